@@ -1,0 +1,105 @@
+"""ctypes binding of libbmxscan.so (C ABI declared in include/bmxscan.h).
+
+There is deliberately no fallback: if the HIP library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C ballermixplus_amd/csrc`)
+importing this module raises, and every compute call raises when no GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbmxscan.so')
+
+
+class BmxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('libbmxscan error %d: %s' % (code, msg))
+        self.code = code
+
+
+class BmxModel(C.Structure):
+    _fields_ = [
+        ('stat', C.c_int32), ('min_count', C.c_int32), ('n_sizes', C.c_int32),
+        ('sizes', C.POINTER(C.c_int32)), ('row_off', C.POINTER(C.c_int32)),
+        ('g', C.POINTER(C.c_double)), ('prop', C.POINTER(C.c_double)),
+        ('nx', C.c_int32), ('x', C.POINTER(C.c_double)),
+        ('nab', C.c_int32), ('abeta', C.POINTER(C.c_double)),
+    ]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/bmxscan.h declares
+PROTOTYPES = {
+    'bmx_version': (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'bmx_last_error': (C.c_char_p, []),
+    'bmx_device_count': (C.c_int, []),
+    'bmx_alpha_cut': (C.c_double, []),
+    'bmx_lut_build': (C.c_int, [C.POINTER(BmxModel), _dp, _dp, C.c_int]),
+    'bmx_scan': (C.c_int, [C.POINTER(BmxModel), _dp, C.c_int32, C.c_int64, _dp, _ip, C.c_int64, _dp, _lp, _lp,
+                           _dp, _ip, _ip, _ip, _ip, C.c_int]),
+    'bmx_ctx_create': (C.c_int, [C.POINTER(_vp), C.c_int]),
+    'bmx_ctx_destroy': (None, [_vp]),
+    'bmx_ctx_set_model': (C.c_int, [_vp, C.POINTER(BmxModel), _dp, C.c_int32]),
+    'bmx_ctx_set_sites': (C.c_int, [_vp, C.c_int64, _dp, _ip]),
+    'bmx_ctx_set_tests': (C.c_int, [_vp, C.c_int64, _dp, _lp, _lp]),
+    'bmx_ctx_scan': (C.c_int, [_vp]),
+    'bmx_ctx_sync': (C.c_int, [_vp]),
+    'bmx_ctx_last_scan_ms': (C.c_int, [_vp, _dp]),
+    'bmx_ctx_fetch': (C.c_int, [_vp, _dp, _ip, _ip, _ip, _ip]),
+    'bmx_ctx_result_ptrs': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    'bmx_ctx_fetch_lut': (C.c_int, [_vp, _dp, _dp]),
+    'bmx_ctx_set_variant': (C.c_int, [_vp, C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libbmxscan.so once; raise if it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('libbmxscan.so not built: %s is missing. Run `make -C %s` '
+                              '(needs hipcc); there is no CPU fallback.' % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BmxError(rc, lib().bmx_last_error().decode('utf-8', 'replace'))
+
+
+def as_dp(a):
+    return a.ctypes.data_as(_dp)
+
+
+def as_ip(a):
+    return a.ctypes.data_as(_ip)
+
+
+def as_lp(a):
+    return a.ctypes.data_as(_lp)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)

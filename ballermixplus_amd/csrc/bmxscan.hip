@@ -1,0 +1,681 @@
+// bmxscan.hip -- libbmxscan.so: gfx950 kernels + C ABI (include/bmxscan.h).
+//
+// Hot path being replaced (reference BalLeRMix+_v1.py, "v1:LINE"):
+//   K1  bb_lut_kernel   <- NormalizedBetaBinom.__init__/get_raw_probs/get_*_normBase  v1:319-433
+//   K2  clr_scan_kernel <- calcBaller                                                v1:436-507
+//
+// K2 formulation.  For a test site t and linkage value A the reference sums, over the sites
+// i of the window with alpha_i = exp(-A*|g_i - t|) >= 1e-8 and g_i != t (v1:454-457),
+//     log(alpha_i*S_i + (1-alpha_i)*g_i) - log(g_i)              (v1:494-499)
+// which equals log(1 + alpha_i*R[x,a][row_i]) with R = S*prop/g - 1 tabulated per (k,n) row.
+// The kernel keeps, per lane, the running PRODUCT  prod_i (1 + alpha_i*R)  (one FMA and one
+// MUL per site and grid pair, no transcendental), pulls the binary exponent out of the product
+// every few sites so it cannot over/underflow, and takes a single log per (t, A, pair).
+// Lanes run over the (x, alpha_beta) pairs, so nothing is reduced across lanes until the
+// final argmax; alpha_i and row_i are computed lanes-over-sites and broadcast.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/bmxscan.h"
+#include "bmx_math.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(BMX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+constexpr int WAVE = 64;
+constexpr int SCAN_THREADS = 256;             // 4 waves per workgroup
+constexpr int LDS_LIMIT_BYTES = 160 * 1024;   // gfx950: 160 KiB per CU
+constexpr double LN2 = 0.693147180559945309417232121458;
+
+// ----------------------------------------------------------------------------- K1
+struct LutParams {
+    int stat, min_count, n_sizes, rows, nx, nab, NP;
+    const int32_t *sizes;
+    const int32_t *row_off;
+    const double *g;
+    const double *prop;
+    const double *x;
+    const double *abeta;
+    double *psel;  // [nx][nab][rows]
+    double *R;     // [nx][nab][rows]
+    double *Rt;    // [rows][NP]   kernel layout: pair index fastest, zero padded
+};
+
+// un-mirrored probability of count k (v1:375-396)
+__device__ double raw_prob(int stat, int k, int n, double a, double b) {
+    if (stat == BMX_STAT_B1) {
+        double pn = bmx::betabinom_pmf(n, n, a, b);
+        return k == 0 ? pn : (1. - pn - pn);                       // v1:382
+    }
+    double p = bmx::betabinom_pmf(k, n, a, b);
+    if (stat == BMX_STAT_B2MAF || stat == BMX_STAT_B0MAF) {
+        p = p + bmx::betabinom_pmf(n - k, n, a, b);                // v1:389
+        if ((n % 2 == 0) && k == n / 2) p = p / 2;                 // v1:391-392
+    }
+    return p;
+}
+
+// numpy's pairwise sum order for a short array given by a generator
+template <class F>
+__device__ double np_sum_gen(int n, F f) {
+    if (n < 8) {
+        double r = 0.;
+        for (int i = 0; i < n; i++) r += f(i);
+        return r;
+    }
+    double r[8];
+    for (int j = 0; j < 8; j++) r[j] = f(j);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += f(i + j);
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += f(i);
+    return res;
+}
+
+__global__ void bb_lut_kernel(LutParams P) {
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    int npairs = P.nx * P.nab;
+    if (gid >= npairs * P.rows) return;
+    int p = gid / P.rows, r = gid % P.rows;
+    int ix = p / P.nab, ia = p % P.nab;
+    int j = 0;
+    while (j + 1 < P.n_sizes && r >= P.row_off[j + 1]) j++;
+    int n = P.sizes[j], k = r - P.row_off[j];
+    double x = P.x[ix], a = P.abeta[ia];
+    double xm = 1. - x;
+    double b1 = a / x - a, b2 = a / xm - a;                       // v1:316
+    double raw = 0.5 * (raw_prob(P.stat, k, n, a, b1) + raw_prob(P.stat, k, n, a, b2));
+    // excluded counts, v1:399-433
+    int m = P.min_count, stat = P.stat;
+    int nex = m;
+    if (stat == BMX_STAT_B2MAF) nex += (m - 1 > 0 ? m - 1 : 0);
+    if (stat == BMX_STAT_B0) nex += 1;
+    if (stat == BMX_STAT_B0MAF) nex += m;
+    auto excl = [&](int i) -> double {
+        int c;
+        if (i < m) c = i;
+        else if (stat == BMX_STAT_B0) c = n;
+        else c = n - m + 1 + (i - m);
+        return 0.5 * (bmx::betabinom_pmf(c, n, a, b1) + bmx::betabinom_pmf(c, n, a, b2));
+    };
+    double base = 1. - np_sum_gen(nex, excl);
+    double psel = raw / base;
+    size_t o = ((size_t)ix * P.nab + ia) * P.rows + r;
+    double R = psel * P.prop[j] / P.g[r] - 1.0;
+    P.psel[o] = psel;
+    P.R[o] = R;
+    P.Rt[(size_t)r * P.NP + p] = R;
+}
+
+// ----------------------------------------------------------------------------- locate
+__global__ void locate_kernel(const double *genpos, int64_t N, const double *test_gen, int64_t M,
+                              int64_t *center) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M) return;
+    double v = test_gen[t];
+    int64_t a = 0, b = N;
+    while (a < b) {
+        int64_t m = (a + b) >> 1;
+        if (genpos[m] < v) a = m + 1; else b = m;
+    }
+    center[t] = a;  // first index with genpos >= test position
+}
+
+// ----------------------------------------------------------------------------- K2
+struct ScanParams {
+    const double *genpos;
+    const uint16_t *row;
+    int64_t N;
+    const double *Rt;  // [rows][NP]
+    int rows, NP, npairs, nslices;
+    const double *A;
+    int nA;
+    const double *test_gen;
+    const int64_t *win_lo;
+    const int64_t *win_hi;
+    const int64_t *center;
+    int64_t M;
+    double zcut;       // alpha >= 1e-8  <=>  A*d <= zcut  (v1:455)
+    int renorm_every;  // sites between exponent extractions
+    int sites_per_block;
+    double *part_T;    // [M][nslices]
+    int32_t *part_lin;
+    int32_t *part_ns;
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// Pull the binary exponent out of a non-negative product; a zero product is sticky (-> -inf).
+__device__ __forceinline__ void renorm(double &acc, int &E) {
+    unsigned hi = (unsigned)__double2hiint(acc);
+    int e = (int)((hi >> 20) & 0x7ffu);
+    E = (e == 0) ? -(1 << 28) : E + (e - 1023);
+    hi = (hi & 0x800fffffu) | 0x3ff00000u;
+    acc = __hiloint2double((int)hi, __double2loint(acc));
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(SCAN_THREADS) void clr_scan_kernel(ScanParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int slice = blockIdx.x % P.nslices;   // blocks b, b+8 share an XCD: one R slice per L2
+    const int64_t chunk = blockIdx.x / P.nslices;
+    const int p = slice * WAVE + lane;
+
+    if (USE_LDS) {
+        const int total = P.rows * WAVE;
+        for (int idx = threadIdx.x; idx < total; idx += SCAN_THREADS)
+            lds_R[idx] = P.Rt[(size_t)(idx >> 6) * P.NP + slice * WAVE + (idx & 63)];
+        __syncthreads();
+    }
+    const double *Rg = P.Rt + slice * WAVE + lane;
+
+    const int64_t t_begin = chunk * P.sites_per_block;
+    const int64_t t_end = min(t_begin + (int64_t)P.sites_per_block, P.M);
+    for (int64_t t = t_begin + wave; t < t_end; t += SCAN_THREADS / WAVE) {
+        const double tg = P.test_gen[t];
+        int64_t lo = max(P.win_lo[t], (int64_t)0);
+        int64_t hi = min(P.win_hi[t], P.N - 1);
+        const int64_t c = P.center[t];
+        double bestT = 0.0;
+        int bestLin = 0x7fffffff, bestNs = 0;
+
+        for (int iA = 0; iA < P.nA; ++iA) {
+            const double Aval = P.A[iA];
+            double acc = 1.0;
+            int E = 0, ns = 0, since = 0;
+            for (int dir = 0; dir < 2; ++dir) {
+                // dir 0: indices c, c+1, ... up to hi;  dir 1: c-1, c-2, ... down to lo
+                int64_t base = dir == 0 ? max(c, lo) : min(c - 1, hi);
+                while (true) {
+                    const int64_t i = dir == 0 ? base + lane : base - lane;
+                    const bool valid = (i >= lo) && (i <= hi);
+                    const double g = valid ? P.genpos[i] : tg;
+                    const double z = Aval * fabs(g - tg);
+                    const bool in = valid && (z <= P.zcut) && (g != tg);
+                    const bool beyond = valid && (z > P.zcut);
+                    const double alpha = in ? exp(-z) : 0.0;
+                    const int rowi = valid ? (int)P.row[i] : 0;
+                    const unsigned long long m_in = __ballot(in);
+                    ns += __popcll(m_in);
+                    const int cnt = m_in ? 64 - __clzll((long long)m_in) : 0;
+                    for (int l = 0; l < cnt; ++l) {
+                        const double a_s = readlane_f64(alpha, l);
+                        const int r_s = __builtin_amdgcn_readlane(rowi, l);
+                        const double R = USE_LDS ? lds_R[r_s * WAVE + lane] : Rg[(size_t)r_s * P.NP];
+                        acc *= fma(a_s, R, 1.0);
+                        if (++since == P.renorm_every) {
+                            renorm(acc, E);
+                            since = 0;
+                        }
+                    }
+                    if (__ballot(beyond) != 0ull || __ballot(valid) != ~0ull) break;
+                    base += dir == 0 ? WAVE : -WAVE;
+                }
+            }
+            if (ns > 0) {
+                renorm(acc, E);
+                const double T = 2.0 * ((double)E * LN2 + log(acc));
+                if (p < P.npairs && T > bestT) {      // strict '>' (v1:501); iA ascending
+                    bestT = T;
+                    bestLin = iA * P.npairs + p;
+                    bestNs = ns;
+                }
+            }
+        }
+        // wave argmax: larger T wins, ties go to the smaller linear index = the reference's
+        // first strict maximum in (A, x, alpha_beta) loop order
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oT = __shfl_xor(bestT, off);
+            const int oL = __shfl_xor(bestLin, off);
+            const int oN = __shfl_xor(bestNs, off);
+            if (oT > bestT || (oT == bestT && oL < bestLin)) {
+                bestT = oT;
+                bestLin = oL;
+                bestNs = oN;
+            }
+        }
+        if (lane == 0) {
+            const size_t o = (size_t)t * P.nslices + slice;
+            P.part_T[o] = bestT;
+            P.part_lin[o] = bestLin;
+            P.part_ns[o] = bestNs;
+        }
+    }
+}
+
+__global__ void finalize_kernel(const double *part_T, const int32_t *part_lin, const int32_t *part_ns,
+                                int nslices, int64_t M, double *clr, int32_t *lin, int32_t *nsites) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M) return;
+    double bT = 0.0;
+    int bL = 0x7fffffff, bN = 0;
+    for (int s = 0; s < nslices; ++s) {
+        const double T = part_T[t * nslices + s];
+        const int L = part_lin[t * nslices + s];
+        if (T > bT || (T == bT && L < bL)) {
+            bT = T;
+            bL = L;
+            bN = part_ns[t * nslices + s];
+        }
+    }
+    const bool none = (bL == 0x7fffffff);
+    clr[t] = none ? 0.0 : bT;
+    lin[t] = none ? -1 : bL;
+    nsites[t] = none ? 0 : bN;
+}
+
+// Largest double z with exp(-z) >= 1e-8 under correct rounding of exp: bisection on the host.
+double compute_zcut() {
+    double lo = 18.0, hi = 19.0;
+    for (;;) {
+        double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        if (exp(-mid) >= 1e-8) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <class T>
+void dfree(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+}  // namespace
+
+// =================================================================================== ctx
+struct bmx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int variant = 0;
+    // model
+    bool has_model = false;
+    int stat = 0, min_count = 1, n_sizes = 0, rows = 0, nx = 0, nab = 0, npairs = 0, NP = 0, nslices = 0, nA = 0;
+    int renorm_every = 16;
+    int32_t *d_sizes = nullptr, *d_row_off = nullptr;
+    double *d_g = nullptr, *d_prop = nullptr, *d_x = nullptr, *d_abeta = nullptr, *d_A = nullptr;
+    double *d_psel = nullptr, *d_R = nullptr, *d_Rt = nullptr;
+    // sites
+    bool has_sites = false;
+    int64_t N = 0;
+    double *d_genpos = nullptr;
+    uint16_t *d_row = nullptr;
+    // tests
+    bool has_tests = false;
+    int64_t M = 0;
+    double *d_test_gen = nullptr;
+    int64_t *d_win_lo = nullptr, *d_win_hi = nullptr, *d_center = nullptr;
+    double *d_part_T = nullptr;
+    int32_t *d_part_lin = nullptr, *d_part_ns = nullptr;
+    double *d_clr = nullptr;
+    int32_t *d_lin = nullptr, *d_nsites = nullptr;
+    double zcut = 0;
+};
+
+namespace {
+
+void free_model(bmx_ctx *c) {
+    dfree(c->d_sizes); dfree(c->d_row_off); dfree(c->d_g); dfree(c->d_prop); dfree(c->d_x);
+    dfree(c->d_abeta); dfree(c->d_A); dfree(c->d_psel); dfree(c->d_R); dfree(c->d_Rt);
+    c->has_model = false;
+}
+void free_sites(bmx_ctx *c) {
+    dfree(c->d_genpos); dfree(c->d_row);
+    c->has_sites = false;
+}
+void free_tests(bmx_ctx *c) {
+    dfree(c->d_test_gen); dfree(c->d_win_lo); dfree(c->d_win_hi); dfree(c->d_center);
+    dfree(c->d_part_T); dfree(c->d_part_lin); dfree(c->d_part_ns);
+    dfree(c->d_clr); dfree(c->d_lin); dfree(c->d_nsites);
+    c->has_tests = false;
+}
+
+template <class T>
+int upload(T *&dst, const T *src, size_t n, hipStream_t s) {
+    HIP_TRY(hipMalloc((void **)&dst, std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+    return BMX_OK;
+}
+
+int validate_model(const bmx_model *m) {
+    if (!m) return fail(BMX_E_INVALID, "model is NULL");
+    if (m->stat < BMX_STAT_B2 || m->stat > BMX_STAT_B1) return fail(BMX_E_INVALID, "unknown statistic id");
+    if (m->n_sizes < 1 || !m->sizes || !m->row_off || !m->g || !m->prop)
+        return fail(BMX_E_INVALID, "model: sizes/row_off/g/prop must be given");
+    if (m->nx < 1 || m->nab < 1 || !m->x || !m->abeta) return fail(BMX_E_INVALID, "model: empty x / alpha_beta grid");
+    if (m->min_count < 0) return fail(BMX_E_INVALID, "model: negative min_count");
+    if (m->row_off[0] != 0) return fail(BMX_E_INVALID, "model: row_off[0] must be 0");
+    for (int j = 0; j < m->n_sizes; j++) {
+        int want = m->stat == BMX_STAT_B1 ? 2 : m->sizes[j] + 1;
+        if (m->sizes[j] < 1 || m->row_off[j + 1] - m->row_off[j] != want)
+            return fail(BMX_E_INVALID, "model: row_off does not match sizes (n+1 rows per size, 2 for B1)");
+    }
+    if (m->row_off[m->n_sizes] > 65535) return fail(BMX_E_LIMIT, "model: more than 65535 LUT rows");
+    for (int i = 0; i < m->nx; i++)
+        if (!(m->x[i] > 0.0 && m->x[i] < 1.0)) return fail(BMX_E_INVALID, "model: x grid must lie in (0,1)");
+    for (int i = 0; i < m->nab; i++)
+        if (!(m->abeta[i] > 0.0)) return fail(BMX_E_INVALID, "model: alpha_beta grid must be positive");
+    return BMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void bmx_version(int *major, int *minor) {
+    if (major) *major = BMX_ABI_VERSION_MAJOR;
+    if (minor) *minor = BMX_ABI_VERSION_MINOR;
+}
+
+const char *bmx_last_error(void) { return g_err.c_str(); }
+
+int bmx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+double bmx_alpha_cut(void) { return compute_zcut(); }
+
+int bmx_ctx_create(bmx_ctx **out, int device) {
+    if (!out) return fail(BMX_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = bmx_device_count();
+    if (n <= 0) return fail(BMX_E_NODEVICE, "no HIP device available (libbmxscan has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(BMX_E_NODEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    bmx_ctx *c = new bmx_ctx();
+    c->device = device;
+    c->zcut = compute_zcut();
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+        hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail(BMX_E_HIP, "stream/event creation failed");
+    }
+    *out = c;
+    return BMX_OK;
+}
+
+void bmx_ctx_destroy(bmx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_model(c);
+    free_sites(c);
+    free_tests(c);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bmx_ctx_set_variant(bmx_ctx *c, int variant) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    c->variant = variant;
+    return BMX_OK;
+}
+
+int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t nA) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    int rc = validate_model(m);
+    if (rc) return rc;
+    if (!A || nA < 1) return fail(BMX_E_INVALID, "empty A grid");
+    for (int i = 0; i < nA; i++)
+        if (!(A[i] > 0.0)) return fail(BMX_E_INVALID, "A grid must be positive");
+    if ((int64_t)nA * m->nx * m->nab > 0x7ffffff0LL) return fail(BMX_E_LIMIT, "grid has more than 2^31 points");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_model(c);
+    c->stat = m->stat; c->min_count = m->min_count; c->n_sizes = m->n_sizes;
+    c->rows = m->row_off[m->n_sizes]; c->nx = m->nx; c->nab = m->nab; c->nA = nA;
+    c->npairs = m->nx * m->nab;
+    c->NP = (c->npairs + WAVE - 1) / WAVE * WAVE;
+    c->nslices = c->NP / WAVE;
+    if ((rc = upload(c->d_sizes, m->sizes, (size_t)m->n_sizes, c->stream))) return rc;
+    if ((rc = upload(c->d_row_off, m->row_off, (size_t)m->n_sizes + 1, c->stream))) return rc;
+    if ((rc = upload(c->d_g, m->g, (size_t)c->rows, c->stream))) return rc;
+    if ((rc = upload(c->d_prop, m->prop, (size_t)m->n_sizes, c->stream))) return rc;
+    if ((rc = upload(c->d_x, m->x, (size_t)m->nx, c->stream))) return rc;
+    if ((rc = upload(c->d_abeta, m->abeta, (size_t)m->nab, c->stream))) return rc;
+    if ((rc = upload(c->d_A, A, (size_t)nA, c->stream))) return rc;
+    size_t tab = (size_t)c->npairs * c->rows;
+    HIP_TRY(hipMalloc((void **)&c->d_psel, tab * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->d_R, tab * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->d_Rt, (size_t)c->rows * c->NP * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(c->d_Rt, 0, (size_t)c->rows * c->NP * sizeof(double), c->stream));
+    LutParams P;
+    P.stat = c->stat; P.min_count = c->min_count; P.n_sizes = c->n_sizes; P.rows = c->rows;
+    P.nx = c->nx; P.nab = c->nab; P.NP = c->NP;
+    P.sizes = c->d_sizes; P.row_off = c->d_row_off; P.g = c->d_g; P.prop = c->d_prop;
+    P.x = c->d_x; P.abeta = c->d_abeta; P.psel = c->d_psel; P.R = c->d_R; P.Rt = c->d_Rt;
+    int threads = 128;
+    int blocks = (int)((tab + threads - 1) / threads);
+    hipLaunchKernelGGL(bb_lut_kernel, dim3(blocks), dim3(threads), 0, c->stream, P);
+    HIP_TRY(hipGetLastError());
+    // How many sites may be multiplied between exponent extractions: every factor
+    // 1 + alpha*R lies in [min(1, 1+Rmin), max(1, 1+Rmax)]; keep the product inside 2^+-1000.
+    std::vector<double> hR(tab);
+    HIP_TRY(hipMemcpyAsync(hR.data(), c->d_R, tab * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double span = 60.0;  // alpha -> 1 with R = -1: factor 1 - alpha >= ~2^-53
+    for (size_t i = 0; i < tab; i++) {
+        double v = hR[i];
+        if (v != v) continue;  // rows absent from the helper file
+        double f = 1.0 + v;
+        if (f > 1.0) span = std::max(span, std::log2(f));
+        else if (f > 0.0) span = std::max(span, std::min(-std::log2(f), 1100.0));
+    }
+    int k = (int)(1000.0 / span);
+    c->renorm_every = std::max(1, std::min(16, k));
+    c->has_model = true;
+    return BMX_OK;
+}
+
+int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t *row) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    if (!c->has_model) return fail(BMX_E_STATE, "set_model must precede set_sites");
+    if (N < 1 || !genpos || !row) return fail(BMX_E_INVALID, "empty site arrays");
+    std::vector<uint16_t> r16((size_t)N);
+    for (int64_t i = 0; i < N; i++) {
+        if (row[i] < 0 || row[i] >= c->rows) return fail(BMX_E_INVALID, "site row index outside the LUT");
+        if (i && genpos[i] < genpos[i - 1]) return fail(BMX_E_INVALID, "genetic positions must be non-decreasing");
+        if (!(genpos[i] == genpos[i])) return fail(BMX_E_INVALID, "NaN genetic position");
+        r16[(size_t)i] = (uint16_t)row[i];
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_sites(c);
+    int rc;
+    if ((rc = upload(c->d_genpos, genpos, (size_t)N, c->stream))) return rc;
+    if ((rc = upload(c->d_row, (const uint16_t *)r16.data(), (size_t)N, c->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->N = N;
+    c->has_sites = true;
+    return BMX_OK;
+}
+
+int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64_t *win_lo,
+                      const int64_t *win_hi) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    if (!c->has_sites) return fail(BMX_E_STATE, "set_sites must precede set_tests");
+    if (M < 1 || !test_gen || !win_lo || !win_hi) return fail(BMX_E_INVALID, "empty test-site arrays");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_tests(c);
+    int rc;
+    if ((rc = upload(c->d_test_gen, test_gen, (size_t)M, c->stream))) return rc;
+    if ((rc = upload(c->d_win_lo, win_lo, (size_t)M, c->stream))) return rc;
+    if ((rc = upload(c->d_win_hi, win_hi, (size_t)M, c->stream))) return rc;
+    HIP_TRY(hipMalloc((void **)&c->d_center, (size_t)M * sizeof(int64_t)));
+    size_t np = (size_t)M * c->nslices;
+    HIP_TRY(hipMalloc((void **)&c->d_part_T, np * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->d_part_lin, np * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&c->d_part_ns, np * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&c->d_clr, (size_t)M * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->d_lin, (size_t)M * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&c->d_nsites, (size_t)M * sizeof(int32_t)));
+    int threads = 256;
+    hipLaunchKernelGGL(locate_kernel, dim3((unsigned)((M + threads - 1) / threads)), dim3(threads), 0, c->stream,
+                       c->d_genpos, c->N, c->d_test_gen, M, c->d_center);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->M = M;
+    c->has_tests = true;
+    return BMX_OK;
+}
+
+int bmx_ctx_scan(bmx_ctx *c) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    if (!c->has_model || !c->has_sites || !c->has_tests) return fail(BMX_E_STATE, "model, sites and tests must be set before scan");
+    HIP_TRY(hipSetDevice(c->device));
+    ScanParams P;
+    P.genpos = c->d_genpos; P.row = c->d_row; P.N = c->N; P.Rt = c->d_Rt;
+    P.rows = c->rows; P.NP = c->NP; P.npairs = c->npairs; P.nslices = c->nslices;
+    P.A = c->d_A; P.nA = c->nA; P.test_gen = c->d_test_gen; P.win_lo = c->d_win_lo; P.win_hi = c->d_win_hi;
+    P.center = c->d_center; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every;
+    P.part_T = c->d_part_T; P.part_lin = c->d_part_lin; P.part_ns = c->d_part_ns;
+    P.sites_per_block = c->M >= 65536 ? 32 : 4;
+    int64_t chunks = (c->M + P.sites_per_block - 1) / P.sites_per_block;
+    int64_t blocks = chunks * c->nslices;
+    if (blocks > 0x7fffffffLL) return fail(BMX_E_LIMIT, "too many workgroups; split the test sites");
+    size_t lds = (size_t)c->rows * WAVE * sizeof(double);
+    bool use_lds = lds <= (size_t)LDS_LIMIT_BYTES && c->variant != 1;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (use_lds) {
+        HIP_TRY(hipFuncSetAttribute((const void *)clr_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(clr_scan_kernel<true>, dim3((unsigned)blocks), dim3(SCAN_THREADS), lds, c->stream, P);
+    } else {
+        hipLaunchKernelGGL(clr_scan_kernel<false>, dim3((unsigned)blocks), dim3(SCAN_THREADS), 0, c->stream, P);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    int threads = 256;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((c->M + threads - 1) / threads)), dim3(threads), 0, c->stream,
+                       c->d_part_T, c->d_part_lin, c->d_part_ns, c->nslices, c->M, c->d_clr, c->d_lin, c->d_nsites);
+    HIP_TRY(hipGetLastError());
+    c->timed = true;
+    return BMX_OK;
+}
+
+int bmx_ctx_sync(bmx_ctx *c) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BMX_OK;
+}
+
+int bmx_ctx_last_scan_ms(bmx_ctx *c, double *ms) {
+    if (!c || !ms) return fail(BMX_E_INVALID, "NULL argument");
+    if (!c->timed) return fail(BMX_E_STATE, "no scan has been launched");
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float f = 0;
+    HIP_TRY(hipEventElapsedTime(&f, c->ev0, c->ev1));
+    *ms = f;
+    return BMX_OK;
+}
+
+int bmx_ctx_result_ptrs(bmx_ctx *c, void **d_clr, void **d_lin, void **d_nsites) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    if (!c->has_tests) return fail(BMX_E_STATE, "no test sites set");
+    if (d_clr) *d_clr = c->d_clr;
+    if (d_lin) *d_lin = c->d_lin;
+    if (d_nsites) *d_nsites = c->d_nsites;
+    return BMX_OK;
+}
+
+int bmx_ctx_fetch(bmx_ctx *c, double *clr, int32_t *ix, int32_t *ia, int32_t *iA, int32_t *nsites) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    if (!c->has_tests || !c->timed) return fail(BMX_E_STATE, "no scan results to fetch");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<int32_t> lin((size_t)c->M);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (clr) HIP_TRY(hipMemcpy(clr, c->d_clr, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost));
+    if (nsites) HIP_TRY(hipMemcpy(nsites, c->d_nsites, (size_t)c->M * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lin.data(), c->d_lin, (size_t)c->M * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int64_t t = 0; t < c->M; t++) {
+        int32_t L = lin[(size_t)t];
+        int32_t a = -1, b = -1, d = -1;
+        if (L >= 0) {
+            d = L / c->npairs;
+            int32_t p = L % c->npairs;
+            a = p / c->nab;
+            b = p % c->nab;
+        }
+        if (ix) ix[t] = a;
+        if (ia) ia[t] = b;
+        if (iA) iA[t] = d;
+    }
+    return BMX_OK;
+}
+
+int bmx_ctx_fetch_lut(bmx_ctx *c, double *psel_out, double *R_out) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    if (!c->has_model) return fail(BMX_E_STATE, "no model set");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    size_t tab = (size_t)c->npairs * c->rows * sizeof(double);
+    if (psel_out) HIP_TRY(hipMemcpy(psel_out, c->d_psel, tab, hipMemcpyDeviceToHost));
+    if (R_out) HIP_TRY(hipMemcpy(R_out, c->d_R, tab, hipMemcpyDeviceToHost));
+    return BMX_OK;
+}
+
+int bmx_lut_build(const bmx_model *m, double *psel_out, double *R_out, int device) {
+    bmx_ctx *c = nullptr;
+    int rc = bmx_ctx_create(&c, device);
+    if (rc) return rc;
+    const double A1 = 1.0;
+    rc = bmx_ctx_set_model(c, m, &A1, 1);
+    if (!rc) rc = bmx_ctx_fetch_lut(c, psel_out, R_out);
+    std::string keep = g_err;
+    bmx_ctx_destroy(c);
+    g_err = keep;
+    return rc;
+}
+
+int bmx_scan(const bmx_model *m, const double *A, int32_t nA, int64_t N, const double *genpos,
+             const int32_t *row, int64_t M, const double *test_gen, const int64_t *win_lo,
+             const int64_t *win_hi, double *clr, int32_t *ix, int32_t *ia, int32_t *iA,
+             int32_t *nsites, int device) {
+    bmx_ctx *c = nullptr;
+    int rc = bmx_ctx_create(&c, device);
+    if (rc) return rc;
+    rc = bmx_ctx_set_model(c, m, A, nA);
+    if (!rc) rc = bmx_ctx_set_sites(c, N, genpos, row);
+    if (!rc) rc = bmx_ctx_set_tests(c, M, test_gen, win_lo, win_hi);
+    if (!rc) rc = bmx_ctx_scan(c);
+    if (!rc) rc = bmx_ctx_fetch(c, clr, ix, ia, iA, nsites);
+    std::string keep = g_err;
+    bmx_ctx_destroy(c);
+    g_err = keep;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,206 @@
+"""Python face of the MI355X scan: the two seams of the reference's hot path.
+
+    NormalizedBetaBinom(InputData, Grids, nofreq, MAF, nosub)       reference BalLeRMix+_v1.py:310-433, called at :793
+    calcBaller(window_indice, testSite, InputData, NeutralSFS,
+               NormalizedBetaBinom, Grids)                          reference BalLeRMix+_v1.py:436-507
+
+keep their names, argument meaning and return values, but run on the GPU through
+libbmxscan.so (include/bmxscan.h).  `scan_batch` is the call the CLI uses: all test
+sites of a chromosome in one launch.  Nothing here computes likelihoods on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BmxModel
+
+STAT_IDS = {'B2': 0, 'B2maf': 1, 'B0': 2, 'B0maf': 3, 'B1': 4}
+
+
+def stat_name(nofreq, MAF, nosub):
+    """The dispatch of v1:336-352."""
+    if nofreq:
+        return 'B1'
+    if MAF:
+        return 'B0maf' if nosub else 'B2maf'
+    return 'B0' if nosub else 'B2'
+
+
+class ModelArrays:
+    """The bmx_model struct plus the numpy arrays that back its pointers."""
+
+    def __init__(self, stat, min_count, sizes, spect, samp_props, xs, abetas):
+        self.stat = stat
+        self.sizes = _lib.i32(sorted(int(n) for n in sizes))
+        per = [2 if stat == 'B1' else int(n) + 1 for n in self.sizes]
+        self.row_off = _lib.i32(np.concatenate(([0], np.cumsum(per))))
+        self.rows = int(self.row_off[-1])
+        g = np.full(self.rows, np.nan)
+        for j, n in enumerate(self.sizes.tolist()):
+            for k in range(per[j]):
+                v = spect.get((k, n))
+                if v is not None:
+                    g[self.row_off[j] + k] = v
+        self.g = _lib.f64(g)
+        self.prop = _lib.f64([samp_props[int(n)] for n in self.sizes])
+        self.x = _lib.f64(xs)
+        self.abeta = _lib.f64(abetas)
+        self.min_count = int(min_count)
+        self._off_of = {int(n): int(o) for n, o in zip(self.sizes, self.row_off[:-1])}
+        self.c = BmxModel(STAT_IDS[stat], self.min_count, len(self.sizes), _lib.as_ip(self.sizes),
+                          _lib.as_ip(self.row_off), _lib.as_dp(self.g), _lib.as_dp(self.prop),
+                          len(self.x), _lib.as_dp(self.x), len(self.abeta), _lib.as_dp(self.abeta))
+
+    def rows_of(self, count, total):
+        """LUT row of every site: row_off[n] + k."""
+        total = np.asarray(total, dtype=np.int64)
+        count = np.asarray(count, dtype=np.int64)
+        un, inv = np.unique(total, return_inverse=True)
+        offs = np.array([self._off_of[int(n)] for n in un], dtype=np.int64)
+        return _lib.i32(offs[inv] + count)
+
+
+class Context:
+    """One resident scan context (one GPU).  Thin wrapper over the bmx_ctx_* calls."""
+
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        _lib.check(self._L.bmx_ctx_create(C.byref(self._h), int(device)))
+        self.device = int(device)
+        self.M = 0
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            self._L.bmx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_model(self, model, As):
+        A = _lib.f64(As)
+        self.model, self.nA = model, len(A)
+        _lib.check(self._L.bmx_ctx_set_model(self._h, C.byref(model.c), _lib.as_dp(A), len(A)))
+
+    def set_sites(self, genpos, rows):
+        g, r = _lib.f64(genpos), _lib.i32(rows)
+        self.N = len(g)
+        _lib.check(self._L.bmx_ctx_set_sites(self._h, len(g), _lib.as_dp(g), _lib.as_ip(r)))
+
+    def set_tests(self, test_gen, win_lo, win_hi):
+        t, lo, hi = _lib.f64(test_gen), _lib.i64(win_lo), _lib.i64(win_hi)
+        self.M = len(t)
+        _lib.check(self._L.bmx_ctx_set_tests(self._h, len(t), _lib.as_dp(t), _lib.as_lp(lo), _lib.as_lp(hi)))
+
+    def set_variant(self, v):
+        _lib.check(self._L.bmx_ctx_set_variant(self._h, int(v)))
+
+    def scan(self):
+        _lib.check(self._L.bmx_ctx_scan(self._h))
+
+    def sync(self):
+        _lib.check(self._L.bmx_ctx_sync(self._h))
+
+    def last_scan_ms(self):
+        ms = C.c_double()
+        _lib.check(self._L.bmx_ctx_last_scan_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def fetch(self):
+        M = self.M
+        clr = np.empty(M, dtype=np.float64)
+        ix, ia, iA, ns = (np.empty(M, dtype=np.int32) for _ in range(4))
+        _lib.check(self._L.bmx_ctx_fetch(self._h, _lib.as_dp(clr), _lib.as_ip(ix), _lib.as_ip(ia),
+                                         _lib.as_ip(iA), _lib.as_ip(ns)))
+        return clr, ix, ia, iA, ns
+
+    def result_ptrs(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(self._L.bmx_ctx_result_ptrs(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def fetch_lut(self):
+        m = self.model
+        shape = (len(m.x), len(m.abeta), m.rows)
+        psel, R = np.empty(shape), np.empty(shape)
+        _lib.check(self._L.bmx_ctx_fetch_lut(self._h, _lib.as_dp(psel), _lib.as_dp(R)))
+        return psel, R
+
+
+class NormalizedBetaBinom:
+    """Drop-in for the reference class of the same name (v1:310-433): same constructor
+    arguments; `get(x, a)` returns the per-site normalised selection probabilities.  The table
+    is built by the device kernel (K1) and stays resident for calcBaller / scan_batch.
+    The device table also folds in the neutral spectrum (R = P_sel*prop/g - 1), which the
+    reference only supplies at calcBaller time, so the device state is created on first use
+    (`bind`), when the NeutralSFS is known."""
+
+    def __init__(self, InputData, Grids, nofreq, MAF, nosub, device=0):
+        self.stat = stat_name(nofreq, MAF, nosub)
+        self.grid_x, self.grid_abeta, self.grid_A = Grids.scan_order()
+        self._data = InputData
+        self._device = device
+        self._bound_to = None
+        self.ctx = None
+        self._psel = None
+        self._key = {}
+        for i, x in enumerate(self.grid_x):
+            for j, a in enumerate(self.grid_abeta):
+                self._key[(x, a)] = (i, j)
+
+    def bind(self, NeutralSFS):
+        """Create (once per NeutralSFS) the resident context: K1 table + site arrays in HBM."""
+        if self._bound_to is NeutralSFS and self.ctx is not None:
+            return self
+        d = self._data
+        if NeutralSFS is None:      # get() before any scan: neutral part is irrelevant to P_sel
+            spect = {(k, int(n)): 1.0 for n in d.sampSizes for k in range(int(n) + 1)}
+            props = {int(n): 1.0 for n in d.sampSizes}
+        else:
+            spect, props = NeutralSFS.spect, NeutralSFS.sampProps
+        self.model = ModelArrays(self.stat, d.minCount, d.sampSizes, spect, props, self.grid_x, self.grid_abeta)
+        self.rows = self.model.rows_of(d.count, d.total)
+        if self.ctx is not None:
+            self.ctx.close()
+        self.ctx = Context(self._device)
+        self.ctx.set_model(self.model, self.grid_A)
+        self.ctx.set_sites(d.genPos, self.rows)
+        self._bound_to = NeutralSFS
+        self._psel = None
+        return self
+
+    def get(self, x, a):
+        """v1:362-363"""
+        if self.ctx is None:
+            self.bind(None)
+        if self._psel is None:
+            self._psel, _ = self.ctx.fetch_lut()
+        i, j = self._key[(x, a)]
+        return self._psel[i, j][self.rows]
+
+
+def scan_batch(sel, test_gen, win_lo, win_hi):
+    """All test sites at once.  Returns (clr f64[M], ix, ia, iA, nsites) with indices into the
+    iteration-order grids held by `sel` (iA == -1: the reference's all-zero row)."""
+    sel.ctx.set_tests(test_gen, win_lo, win_hi)
+    sel.ctx.scan()
+    return sel.ctx.fetch()
+
+
+def calcBaller(window_indice, testSite, InputData, NeutralSFS, NormalizedBetaBinom, Grids):
+    """Drop-in for v1:436-507 (one test site).  `window_indice` must be a contiguous index
+    range, which is all the reference ever passes (v1:538,572,589,606).  Returns
+    [T, x, abeta, A, nSites] with the grid's own Python objects, or the all-zero list."""
+    w = np.asarray(window_indice)
+    NormalizedBetaBinom.bind(NeutralSFS)
+    clr, ix, ia, iA, ns = scan_batch(NormalizedBetaBinom, [float(testSite)], [int(w[0])], [int(w[-1])])
+    if iA[0] < 0:
+        return [0., 0., 0., 0., 0.]
+    s = NormalizedBetaBinom
+    return [float(clr[0]), s.grid_x[ix[0]], s.grid_abeta[ia[0]], s.grid_A[iA[0]], int(ns[0])]

@@ -1,0 +1,223 @@
+"""Host-side mirror of the reference's input / neutral-model / grid classes.
+
+These keep the reference's names, argument meaning, messages and exit behaviour
+(reference BalLeRMix+_v1.py, cited as v1:LINE) because the CLI built on them must
+be a drop-in: same flags, same files in, same files out.  None of this is on the
+hot path -- it only produces the arrays the HIP kernels consume.
+"""
+import sys
+
+import numpy as np
+
+
+class InputData:
+    """v1:8-131.  Arrays: position (int), genPos (f64), count (k), total (n)."""
+
+    def __init__(self, infile, nofreq=False, MAF=False, nosub=False, minCount=1, phys=False, Rrate=1e-6):
+        self.numSites = 0
+        self.minCount = minCount
+        self.Rrate = Rrate
+        pos_type = 1 - int(phys)     # column holding the coordinate: 0 physical, 1 genetic (v1:18)
+        position, genPos, count, total = self._read(infile, pos_type, Rrate, nofreq)
+        self.count = np.array(count)
+        self.total = np.array(total)
+        self.genPos = np.array(genPos)
+        self.position = np.array(position)
+        if not nofreq:
+            _stat = '%s%s' % (['B_2', 'B_0'][nosub], ['', 'MAF'][MAF])
+            if nosub:                                                     # v1:41-50
+                if np.sum(self.count == self.total) > 0:
+                    print(f'You have chosen to compute {_stat}. Substitutions (x==n) in the input will be ignored.')
+                    keep = np.where(self.count != self.total)
+                    self.count = self.count[keep]
+                    self.total = self.total[keep]
+                    self.genPos = self.genPos[keep]
+                    self.position = self.position[keep]
+                    self.numSites = len(self.count)
+            if MAF:                                                       # v1:53-59
+                if np.sum(self.count > self.total / 2) > 0:
+                    print(f'Input data includes non-MAF site/s (frequency >= 0.5) despite choosing to use {_stat} (with --MAF). These frequencies will be folded for following analyses.')
+                    self.count = np.where(self.count > self.total / 2, (self.total - self.count), self.count)
+                self.minCount = int(self.count[self.count > 0].min())
+            else:                                                         # v1:60-74
+                if np.sum(self.count == 0) != 0:
+                    print('Please make sure to include derived allele frequency only. Sites with zero derived alleles (x==0) should not be included in your input.')
+                    sys.exit()
+                self.minCount = int(self.count.min())
+        else:
+            self.minCount = int(minCount)
+        self.sampSizes = set(self.total.tolist())                         # v1:76
+
+    def _read(self, infile, pos_type, Rrate, nofreq):
+        """readCounts v1:113-131 / readPolyCalls v1:80-110 (same text loop)."""
+        position, genPos, count, total = [], [], [], []
+        translate = False
+        with open(infile, 'r') as sites:
+            next(sites)                                                   # header
+            for l in sites:
+                l = l.strip().split('\t')
+                self.numSites += 1
+                physPos, k, n = int(float(l[0])), int(l[2]), int(l[3])
+                if nofreq:                                                # v1:91-100
+                    if not translate:
+                        if k not in (0, 1):
+                            print('Input includes different variant counts despite choosing not to use allele frequencies (with --noFreq). All sites with counts smaller than substitutions will be considered as polymorphic. All sites with identical counts as sample sizes will be substitutions.')
+                            translate = True
+                            k = (k != n)
+                    else:
+                        k = (k != n)
+                sitepos = float(l[pos_type]) * (1 - pos_type) * Rrate + float(l[pos_type]) * (pos_type)
+                count.append(k)
+                total.append(n)
+                genPos.append(sitepos)
+                position.append(physPos)
+        return position, genPos, count, total
+
+
+class Grids:
+    """v1:134-175.  Lists keep the reference's Python objects (ints stay ints, 1e3 stays a
+    float) because the output prints them with repr (v1:607)."""
+
+    DEFAULT_ABETA = ([0.001, 0.01, 0.05, 0.1, 0.2, 0.5, 0.8] + [i for i in range(1, 10)] +
+                     [5 * i for i in range(1, 20)] + [10 * i for i in range(10, 21)] +
+                     [300, 500, 1e3, 1e4, 1e6, 1e9])
+
+    def __init__(self, x, abeta, bal, pos, seqA, listA):
+        if x is not None:
+            _xGrid = [float(x)]
+        else:
+            _xGrid = [.05 * i for i in range(1, 11)]
+        if abeta is not None:
+            try:
+                _abetaGrid = [float(abeta)]
+            except Exception:
+                print(f'The value for "a" provided ({abeta}) is not legitimate. Using the default grid instead.')
+                _abetaGrid = list(self.DEFAULT_ABETA)
+        elif bal:
+            _abetaGrid = ([i for i in range(1, 10)] + [5 * i for i in range(1, 20)] +
+                          [10 * i for i in range(10, 21)] + [300, 500, 1e3, 1e4, 1e6, 1e9])
+        elif pos:
+            _abetaGrid = [0.001, 0.01, 0.05, 0.1, 0.2, 0.5, 0.8]
+            _xGrid = [.1 * i for i in range(1, 11)]
+        else:
+            _abetaGrid = list(self.DEFAULT_ABETA)
+        if not seqA and not listA:
+            _AGrid = ([100 * i for i in range(1, 12)] + [200 * i for i in range(6, 13)] +
+                      [500 * i for i in range(5, 10)] + [1000 * i for i in range(5, 11)] + [1e6, 1e8])
+        elif listA:
+            _AGrid = [float(v) for v in listA.split(',')]
+        else:
+            # The reference raises here (float range + 'Atep' typo, v1:169-171; SURVEY 5 defect 1);
+            # this is the evident intent: Amin, Amin+Astep, ... up to Amax, as floats.
+            Amin, Amax, Astep = [float(v) for v in seqA.split(',')]
+            nstep = int(round((Amax - Amin) / Astep))
+            _AGrid = [Amin + Astep * i for i in range(nstep + 1)]
+        self.x = _xGrid
+        self.A = _AGrid
+        self.abeta = _abetaGrid
+
+    def scan_order(self):
+        """Iteration order of the grid search: calcBaller loops `for A in set(Grids.A)`,
+        `for x in set(Grids.x)`, `for abeta in set(Grids.abeta)` (v1:453,473,474).  CPython's set
+        order for ints/floats is deterministic, so list(set(...)) here is that same order and
+        the strict '>' argmax (v1:501) resolves ties identically."""
+        return list(set(self.x)), list(set(self.abeta)), list(set(self.A))
+
+
+class NeutralSFS:
+    """v1:180-304: neutral spectrum / configuration helper file."""
+
+    def __init__(self, spectfile, nofreq, MAF, nosub):
+        self.spect = {}
+        self.sampSizes = set()
+        self.probs = []
+        self.logProbs = []
+        self.sampProps = {}
+        self.propSizes = []
+        if nofreq:
+            self.readConfig(spectfile)
+        else:
+            self.readSpect(spectfile, MAF, nosub)
+
+    def readSpect(self, spectfile, MAF, nosub):                           # v1:183-223
+        g = {}
+        N = []
+        checksum = 0.
+        with open(spectfile, 'r') as spect:
+            for l in spect:
+                l = l.strip().split('\t')
+                x = int(l[0])
+                n = int(l[1])
+                f = float(l[2])
+                if MAF:
+                    if nosub and x == 0:
+                        print('You have chosen to compute B_0maf. Please do not account for sites with zero counts (x==0) in your input.')
+                        sys.exit()
+                    if x < (n / 2 + 1):
+                        g[(x, n)] = f
+                    else:
+                        print('You have indicated to use minor allele frequencies (--MAF) but provided SFS based on polarized allele frequency. This SFS will be folded accordingly.')
+                        if (n - x, n) in g:
+                            g[(n - x, n)] += f
+                        else:
+                            g[(n - x, n)] = f
+                else:
+                    if nosub and x == n:
+                        print('You have chosen to compute B_2maf. Please do not account for substitutions (derived allele count x == n) in your input.')
+                        sys.exit()
+                    g[(x, n)] = f
+                checksum += f
+                N.append(n)
+                if n not in self.sampProps:
+                    self.sampProps[n] = 0.
+                self.sampProps[n] += f
+        if not np.isclose(checksum, 1.):
+            print(f'Fraction of sites do not add up to 1! Sum = {checksum}. Please double-check your inputs.')
+            sys.exit()
+        self.spect = g
+        self.sampSizes = set(N)
+
+    def readConfig(self, spectfile):                                      # v1:227-250
+        N = []
+        checksum = 0.
+        g = {}
+        with open(spectfile, 'r') as spect:
+            for l in spect:
+                l = l.strip().split('\t')
+                n = int(l[0])
+                s = float(l[1])
+                p = float(l[2])
+                print(('Substitutions: %s ; polymorphisms: %s' % (s, p)))
+                checksum += (s + p)
+                g = {(0, n): s, (1, n): p}     # as in the reference: only the last line survives
+                N.append(n)
+                if n not in self.sampProps:
+                    self.sampProps[n] = 0
+                self.sampProps[n] += (s + p)
+        if not checksum == 1.:
+            print(f'Fraction of sites do not add up to 1! Sum = {checksum}. Please double-check your inputs.')
+            sys.exit()
+        self.spect = g
+        self.sampSizes = set(N)
+
+    def get_neut_probs(self, data):                                       # v1:278-304
+        """Checks that every (k, n) in the input is covered by the helper file.  The per-site
+        arrays of the reference are replaced by the (k,n)-indexed table handed to the kernels
+        (SelectionTable); probs/logProbs/propSizes are still filled for API compatibility."""
+        combos = set(zip(data.count.tolist(), data.total.tolist()))
+        if not combos.issubset(set(self.spect.keys())):
+            print('Input data includes sample counts and sizes not included in the helper file. Please double-check your inputs.')
+            sys.exit()
+        if len(self.probs) == 0:
+            lut = {c: self.spect[c] for c in combos}
+            key = data.count.astype(np.int64) * (int(data.total.max()) + 1) + data.total.astype(np.int64)
+            uk, inv = np.unique(key, return_inverse=True)
+            vals = np.array([lut[(int(u) // (int(data.total.max()) + 1), int(u) % (int(data.total.max()) + 1))]
+                             for u in uk])
+            self.probs = vals[inv]
+        assert len(self.probs) == data.numSites
+        if len(self.logProbs) == 0:
+            self.logProbs = np.log(self.probs)
+        if len(self.propSizes) == 0:
+            un, inv = np.unique(data.total, return_inverse=True)
+            self.propSizes = np.array([self.sampProps[int(n)] for n in un], dtype=np.float64)[inv]

@@ -1,0 +1,193 @@
+"""Scan driver: the reference's `class Scan` (BalLeRMix+_v1.py:510-640) with the per-site
+calcBaller loop replaced by one batched GPU launch per input file.
+
+The four window modes only differ in which test sites they visit and which
+inclusive index window [start_i, end_i] each one gets; those are generated on the
+host exactly as the reference's loops do (they are O(N) two-pointer walks), then all
+test sites go to the device together.  Output rows are formatted in Python from
+the grid's own objects so that repr matches the reference byte for byte (v1:607).
+"""
+import sys
+from datetime import datetime
+from math import floor
+
+import numpy as np
+
+from . import engine
+
+HEADER = 'physPos\tgenPos\tCLR\tx_hat\ts_hat\tA_hat\tnSites\n'
+
+
+class TestSites:
+    """Test sites of one scan, in output order.  `na_rows` holds positions in the output where
+    the reference prints an 'NA' row instead of scanning (v1:534-536)."""
+
+    def __init__(self):
+        self.phys, self.gen_label, self.test_gen, self.lo, self.hi = [], [], [], [], []
+        self.na_rows = {}      # output position -> preformatted line
+        self.order = []        # output position of each scanned site
+
+    def add(self, phys, gen_label, test_gen, lo, hi):
+        self.order.append(len(self.order) + len(self.na_rows))
+        self.phys.append(phys)
+        self.gen_label.append(gen_label)
+        self.test_gen.append(float(test_gen))
+        self.lo.append(int(lo))
+        self.hi.append(int(hi))
+
+    def add_na(self, line):
+        self.na_rows[len(self.order) + len(self.na_rows)] = line
+
+    def __len__(self):
+        return len(self.order)
+
+
+def sites_alpha(data, s):
+    """_alpha, v1:598-610: every int(s)-th site, window = all sites."""
+    ts = TestSites()
+    N = data.numSites
+    step = int(s)
+    i = 0
+    while i < N:
+        ts.add(data.position[int(i)], data.genPos[int(i)], data.genPos[int(i)], 0, N - 1)
+        i += step
+    return ts
+
+
+def sites_site_based(data, r, s):
+    """_siteBased, v1:580-594: r sites to the left, r+1 to the right (end inclusive)."""
+    ts = TestSites()
+    N = data.numSites
+    i = 0
+    while i < N:
+        start_i = max(0, i - r)
+        end_i = min(N - 1, i + r + 1)
+        w = np.arange(start_i, end_i + 1, dtype=int)      # as the reference builds it
+        ts.add(data.position[int(i)], data.genPos[int(i)], data.genPos[int(i)], w[0], w[-1])
+        i += s
+    return ts
+
+
+def sites_fix_center(data, w, s):
+    """_fixSize_siteCenter, v1:549-577: w-nt window centred on every int(s)-th site."""
+    ts = TestSites()
+    N = data.numSites
+    pos = data.position
+    i = 0
+    start_i = 0
+    end_i = 0
+    while i < N:
+        testSite = pos[i]
+        start = max(0, testSite - w / 2)
+        end = min(testSite + w / 2, pos[-1])
+        while pos[start_i] < start:
+            start_i += 1
+        while end_i < N:
+            if pos[end_i] < end:
+                end_i += 1
+            else:
+                break
+        if end_i < start_i:
+            print(start, start_i, end, end_i)
+            sys.exit(1)
+        end_i = min(end_i, N - 1)
+        ts.add(testSite, data.genPos[i], data.genPos[i], start_i, end_i)
+        i += int(s)
+    return ts
+
+
+def sites_fix_nocenter(data, w, s):
+    """_fixSize_noCenter, v1:513-545: test positions every s nt, window one step wide."""
+    ts = TestSites()
+    N = data.numSites
+    pos = data.position
+    start = int(floor(2 * float(pos[0]) / w) * (w / 2))
+    end = start + s
+    midpos = start + s / 2
+    start_i = 0
+    end_i = 0
+    pos_i = 0
+    while midpos <= pos[-1]:
+        while pos[start_i] < start:
+            start_i += 1
+        while pos[pos_i] < midpos:
+            pos_i += 1
+        while (end_i + 1) < N:
+            if pos[end_i] < end:
+                end_i += 1
+            else:
+                break
+        gen_site = midpos * data.Rrate
+        if start_i >= end_i:
+            ts.add_na('%d\t%g\t0\tNA\tNA\tNA\t0\n' % (midpos, gen_site))
+        else:
+            ts.add(midpos, midpos * data.Rrate, gen_site, start_i, end_i)
+        start += s
+        midpos += s
+        end += s
+    return ts
+
+
+def format_row(phys, gen_label, clr, ix, ia, iA, ns, sel):
+    """The f-string of v1:540,574,591,607.  All-zero row when nothing beat Tmax = 0 (v1:451)."""
+    if isinstance(gen_label, np.floating):
+        gen_label = float(gen_label)
+    if isinstance(phys, np.floating):
+        phys = float(phys)
+    if iA < 0:
+        return f'{phys}\t{gen_label}\t0.0\t0.0\t0.0\t0.0\t0.0\n'
+    return (f'{phys}\t{gen_label}\t{float(clr)}\t{sel.grid_x[ix]}\t{sel.grid_abeta[ia]}\t'
+            f'{sel.grid_A[iA]}\t{int(ns)}\n')
+
+
+def write_rows(outfile, ts, results, sel):
+    clr, ix, ia, iA, ns = results
+    total = len(ts) + len(ts.na_rows)
+    lines = [None] * total
+    for pos, line in ts.na_rows.items():
+        lines[pos] = line
+    for j, pos in enumerate(ts.order):
+        lines[pos] = format_row(ts.phys[j], ts.gen_label[j], clr[j], int(ix[j]), int(ia[j]), int(iA[j]), ns[j], sel)
+    with open(outfile, 'w') as scores:
+        scores.write(HEADER)
+        scores.writelines(lines)
+
+
+class Scan:
+    """v1:510-640: same constructor, same dispatch, same messages."""
+
+    def __init__(self, InputData, NeutralSFS, NormalizedBetaBinom, Grids, outfile, fixSize=False, r=0, s=1,
+                 phys=False, noCenter=False, runner=None):
+        if fixSize:
+            print('You\'ve chosen to fix the size (in nt) of sliding window for scanning.')
+            if r == 0:
+                print('Please set a window width in nt with "-w" or "--window" command.')
+                sys.exit()
+            if not phys:
+                print(f'Please make sure to use physical positions as coordinates if fixed-length windows are chosen (--fixSize). Scan will continue with physical positions with a rec rate of {InputData.Rrate} cM/nt.')
+                phys = True
+            w = float(r)
+            if noCenter:
+                print(('Computing LR on %.3f kb windows on every %s nt. Using physical positions by default.' % (w / 1e3, s)))
+                ts = sites_fix_nocenter(InputData, w, s)
+            else:
+                print(('Computing LR on %.3f kb windows on every %g informative sites. Using physical positions by default.' % (w / 1e3, s)))
+                ts = sites_fix_center(InputData, w, s)
+        elif r != 0:
+            print(('Computing LR on every %s site/s, with a radius of %g informative sites on either side.' % (s, r)))
+            ts = sites_site_based(InputData, r, s)
+        else:
+            print(('Computing LR on every %s site/s, using informative sites with exp(-A*dist) >= 1e-8.' % (s)))
+            ts = sites_alpha(InputData, s)
+        print(("writing output to %s" % (outfile)))
+        NormalizedBetaBinom.bind(NeutralSFS)
+        run = runner or engine.scan_batch
+        if len(ts):
+            results = run(NormalizedBetaBinom, ts.test_gen, ts.lo, ts.hi)
+        else:
+            results = (np.zeros(0), np.zeros(0, int), np.zeros(0, int), np.zeros(0, int), np.zeros(0, int))
+        self.test_sites = ts
+        self.results = results
+        if outfile is not None and results is not None:
+            write_rows(outfile, ts, results, NormalizedBetaBinom)
+        print(f'{datetime.now()}. Scan finished.')

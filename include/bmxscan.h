@@ -1,0 +1,137 @@
+/* bmxscan.h -- C ABI of libbmxscan.so, the MI355X (gfx950) composite-likelihood scan.
+ *
+ * The reference (bioXiaoheng/BallerMixPlus, BalLeRMix+_v1.py) is a single Python
+ * script with no FFI of its own; the seam this library drops into is the pair of
+ * Python calls on its hot path:
+ *
+ *   NormalizedBetaBinom(InputData, Grids, nofreq, MAF, nosub)      BalLeRMix+_v1.py:793 (class at :310-433)
+ *   calcBaller(window_indice, testSite, InputData, NeutralSFS,
+ *              NormalizedBetaBinom, Grids) -> [T, x, abeta, A, nSites]
+ *                                                                   BalLeRMix+_v1.py:539,573,590,606 (def at :436-507)
+ *
+ * Every entry point is extern "C", takes plain pointers and sizes, never throws,
+ * never exits the process and retains no caller memory after it returns.
+ * Return value: 0 on success, a negative BMX_E_* code otherwise; the message is
+ * available from bmx_last_error() (thread-local).  All host buffers are
+ * caller-allocated, C-contiguous, native endian.  There is NO CPU fallback: when
+ * no HIP device is usable every compute entry point fails with BMX_E_NODEVICE.
+ */
+#ifndef BMXSCAN_H
+#define BMXSCAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMX_ABI_VERSION_MAJOR 1
+#define BMX_ABI_VERSION_MINOR 0
+
+enum {
+    BMX_OK = 0,
+    BMX_E_INVALID = -1,   /* bad argument (null pointer, size, unsorted positions, ...) */
+    BMX_E_NODEVICE = -2,  /* no usable HIP device / device index out of range */
+    BMX_E_HIP = -3,       /* a HIP runtime call failed; see bmx_last_error() */
+    BMX_E_LIMIT = -4,     /* a documented size limit was exceeded */
+    BMX_E_STATE = -5      /* call order violated (e.g. scan before model/sites were set) */
+};
+
+/* Which B statistic the selection table is built for.
+ * Replaces the (nofreq, MAF, nosub) flag triple of NormalizedBetaBinom.__init__
+ * (BalLeRMix+_v1.py:319, dispatch at :336-352). */
+enum {
+    BMX_STAT_B2 = 0,     /* default                      v1:351-352, normBase :399-404 */
+    BMX_STAT_B2MAF = 1,  /* --MAF                        v1:344-345, :389-392, :406-413 */
+    BMX_STAT_B0 = 2,     /* --noSub                      v1:348-349, :419-425 */
+    BMX_STAT_B0MAF = 3,  /* --noSub --MAF                v1:341-342, :427-433 */
+    BMX_STAT_B1 = 4      /* --noFreq                     v1:337-338, :378-383, :415-417 */
+};
+
+/* The model the grid search runs over.  It carries what calcBaller reads from
+ * InputData / NeutralSFS / Grids, re-indexed by LUT row instead of by site:
+ * a site with derived count k and sample size sizes[j] maps to row
+ * row_off[j] + k  (B1: k in {0,1}).  rows = row_off[n_sizes]. */
+typedef struct bmx_model {
+    int32_t stat;            /* BMX_STAT_* */
+    int32_t min_count;       /* InputData.minCount (v1:59,74) */
+    int32_t n_sizes;         /* number of distinct sample sizes (InputData.sampSizes, v1:76) */
+    const int32_t *sizes;    /* [n_sizes] sample sizes n */
+    const int32_t *row_off;  /* [n_sizes+1] first LUT row of each size */
+    const double *g;         /* [rows] neutral probability NeutralSFS.spect[(k,n)] (v1:208,292);
+                                NaN for (k,n) absent from the helper file (never referenced by a site) */
+    const double *prop;      /* [n_sizes] NeutralSFS.sampProps[n] (v1:212-214,304) */
+    int32_t nx;              /* grids in the reference's ITERATION order: list(set(Grids.x)) etc. */
+    const double *x;         /* [nx]   (v1:473) */
+    int32_t nab;
+    const double *abeta;     /* [nab]  (v1:474) */
+} bmx_model;
+
+/* ---- library-level queries -------------------------------------------------------- */
+void bmx_version(int *major, int *minor);
+const char *bmx_last_error(void);
+/* Number of visible HIP devices (0 when none / no driver). */
+int bmx_device_count(void);
+/* The window cut-off in the exponent domain: largest double z with exp(-z) >= 1e-8, so that the
+ * reference's predicate `np.exp(-A*dist) >= 1e-8` (BalLeRMix+_v1.py:454-455) is `A*dist <= z`. */
+double bmx_alpha_cut(void);
+
+/* ---- one-shot entry points (host buffers in, host buffers out) ---------------------- */
+
+/* Replaces NormalizedBetaBinom.__init__ (BalLeRMix+_v1.py:319-359) + get() (:362-363).
+ * Runs the device lgamma / beta-binomial kernel and returns, for every grid pair
+ * and LUT row,
+ *     psel_out[ix][ia][row] = normProbs[(x,a)] value of a site on that row      (optional, may be NULL)
+ *     R_out   [ix][ia][row] = psel * prop(n) / g(k,n) - 1                       (optional, may be NULL)
+ * so that calcBaller's mixture log-ratio of one site is log1p(alpha * R) (v1:494-499). */
+int bmx_lut_build(const bmx_model *m, double *psel_out, double *R_out, int device);
+
+/* Replaces the calcBaller call of every Scan mode (BalLeRMix+_v1.py:539,573,590,606).
+ *   A[nA]        linkage grid in iteration order list(set(Grids.A))                    (v1:453)
+ *   genpos[N]    InputData.genPos, non-decreasing;  row[N] LUT row of each site
+ *   test_gen[M]  genetic position of each test site (testSite argument, v1:436)
+ *   win_lo/hi[M] inclusive index bounds of window_indice (0, N-1 for the default mode)
+ * Outputs, length M:  clr = Tmax[0];  ix/ia/iA = indices of x_hat / alpha_hat / A_hat in the
+ * grids passed in;  nsites = Tmax[4].  iA == -1 (with clr = 0, ix = ia = -1, nsites = 0)
+ * means no grid point had T > 0: the reference prints its all-zero initial row (v1:451). */
+int bmx_scan(const bmx_model *m, const double *A, int32_t nA, int64_t N, const double *genpos,
+             const int32_t *row, int64_t M, const double *test_gen, const int64_t *win_lo,
+             const int64_t *win_hi, double *clr, int32_t *ix, int32_t *ia, int32_t *iA,
+             int32_t *nsites, int device);
+
+/* ---- resident-context entry points ------------------------------------------------- */
+/* Same computation split so that inputs stay resident in HBM across scans (one context per
+ * process per GPU; the multi-GPU driver shards test sites across processes). */
+typedef struct bmx_ctx bmx_ctx;
+
+int bmx_ctx_create(bmx_ctx **out, int device);
+void bmx_ctx_destroy(bmx_ctx *c);
+/* Build the selection table on the device (K1) and keep it resident. */
+int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t nA);
+/* Copy the site arrays of one chromosome to the device. */
+int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t *row);
+/* Copy test sites + window bounds to the device (and locate each test site). */
+int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64_t *win_lo,
+                      const int64_t *win_hi);
+/* Launch the scan (K2 + argmax finalisation) on the context's stream; asynchronous. */
+int bmx_ctx_scan(bmx_ctx *c);
+/* Block until the stream is idle. */
+int bmx_ctx_sync(bmx_ctx *c);
+/* Milliseconds the last bmx_ctx_scan spent in the scan kernel(s), from HIP events
+ * recorded on the context's stream (valid after bmx_ctx_sync). */
+int bmx_ctx_last_scan_ms(bmx_ctx *c, double *ms);
+/* Copy results of the last scan to host buffers of length M. */
+int bmx_ctx_fetch(bmx_ctx *c, double *clr, int32_t *ix, int32_t *ia, int32_t *iA, int32_t *nsites);
+/* Device addresses of the last scan's results: clr f64[M], lin i32[M] (linear grid index
+ * (iA*nx + ix)*nab + ia, or -1), nsites i32[M].  Valid until the next set_tests/destroy;
+ * used for the RCCL gather without a host round trip. */
+int bmx_ctx_result_ptrs(bmx_ctx *c, void **d_clr, void **d_lin, void **d_nsites);
+/* Copy the resident tables back: psel/R as in bmx_lut_build (either may be NULL). */
+int bmx_ctx_fetch_lut(bmx_ctx *c, double *psel_out, double *R_out);
+/* Choose the scan kernel variant (0 = default). For A/B measurements only. */
+int bmx_ctx_set_variant(bmx_ctx *c, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMXSCAN_H */
