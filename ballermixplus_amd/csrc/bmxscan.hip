@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -41,6 +42,21 @@ int fail(int code, const std::string &msg) {
             return fail(BMX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
     } while (0)
 
+// BMX_TRACE=1 in the environment prints one line per stage to stderr (diagnostics only)
+bool trace_on() {
+    static int on = -1;
+    if (on < 0) on = getenv("BMX_TRACE") ? 1 : 0;
+    return on == 1;
+}
+#define TRACE(...)                                   \
+    do {                                             \
+        if (trace_on()) {                            \
+            fprintf(stderr, "[bmx] " __VA_ARGS__);   \
+            fprintf(stderr, "\n");                   \
+            fflush(stderr);                          \
+        }                                            \
+    } while (0)
+
 constexpr int WAVE = 64;
 constexpr int SCAN_THREADS = 256;             // 4 waves per workgroup
 constexpr int LDS_LIMIT_BYTES = 160 * 1024;   // gfx950: 160 KiB per CU
@@ -60,38 +76,11 @@ struct LutParams {
     double *Rt;    // [rows][NP]   kernel layout: pair index fastest, zero padded
 };
 
-// un-mirrored probability of count k (v1:375-396)
-__device__ double raw_prob(int stat, int k, int n, double a, double b) {
-    if (stat == BMX_STAT_B1) {
-        double pn = bmx::betabinom_pmf(n, n, a, b);
-        return k == 0 ? pn : (1. - pn - pn);                       // v1:382
-    }
-    double p = bmx::betabinom_pmf(k, n, a, b);
-    if (stat == BMX_STAT_B2MAF || stat == BMX_STAT_B0MAF) {
-        p = p + bmx::betabinom_pmf(n - k, n, a, b);                // v1:389
-        if ((n % 2 == 0) && k == n / 2) p = p / 2;                 // v1:391-392
-    }
-    return p;
-}
-
-// numpy's pairwise sum order for a short array given by a generator
-template <class F>
-__device__ double np_sum_gen(int n, F f) {
-    if (n < 8) {
-        double r = 0.;
-        for (int i = 0; i < n; i++) r += f(i);
-        return r;
-    }
-    double r[8];
-    for (int j = 0; j < 8; j++) r[j] = f(j);
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8)
-        for (int j = 0; j < 8; j++) r[j] += f(i + j);
-    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res += f(i);
-    return res;
-}
-
+// One thread per (grid pair, LUT row).  The thread needs the beta-binomial pmf at the site's own
+// count (folded / B_1 forms, v1:375-396) and at the counts excluded from the support
+// (v1:399-433), each for b(x) and b(1-x).  All of them go through ONE inlined pmf call site
+// inside nested loops: the pmf body is large, and gfx950 device-function calls from a partially
+// active wave proved unusable here (hang), so nothing in this kernel is an out-of-line call.
 __global__ void bb_lut_kernel(LutParams P) {
     int gid = blockIdx.x * blockDim.x + threadIdx.x;
     int npairs = P.nx * P.nab;
@@ -100,28 +89,58 @@ __global__ void bb_lut_kernel(LutParams P) {
     int ix = p / P.nab, ia = p % P.nab;
     int j = 0;
     while (j + 1 < P.n_sizes && r >= P.row_off[j + 1]) j++;
-    int n = P.sizes[j], k = r - P.row_off[j];
-    double x = P.x[ix], a = P.abeta[ia];
-    double xm = 1. - x;
-    double b1 = a / x - a, b2 = a / xm - a;                       // v1:316
-    double raw = 0.5 * (raw_prob(P.stat, k, n, a, b1) + raw_prob(P.stat, k, n, a, b2));
-    // excluded counts, v1:399-433
-    int m = P.min_count, stat = P.stat;
-    int nex = m;
+    const int n = P.sizes[j], k = r - P.row_off[j];
+    const double x = P.x[ix], a = P.abeta[ia];
+    const double xm = 1. - x;
+    const double b1 = a / x - a, b2 = a / xm - a;                 // v1:316
+    const int m = P.min_count, stat = P.stat;
+    const bool maf = (stat == BMX_STAT_B2MAF || stat == BMX_STAT_B0MAF);
+    int nex = m;                                                  // excluded counts, v1:399-433
     if (stat == BMX_STAT_B2MAF) nex += (m - 1 > 0 ? m - 1 : 0);
     if (stat == BMX_STAT_B0) nex += 1;
     if (stat == BMX_STAT_B0MAF) nex += m;
-    auto excl = [&](int i) -> double {
+    // numpy's pairwise summation of the excluded probabilities, streamed (np.sum, v1:402)
+    const int nblk = nex < 8 ? 0 : nex - (nex % 8);
+    double r8[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+    double res = 0.;
+    double raw = 0.;
+    for (int it = 0; it <= nex; ++it) {
+        const bool site = (it == nex);
         int c;
-        if (i < m) c = i;
+        if (site) c = (stat == BMX_STAT_B1) ? n : k;              // B_1 uses pmf(n) (v1:382)
+        else if (it < m) c = it;
         else if (stat == BMX_STAT_B0) c = n;
-        else c = n - m + 1 + (i - m);
-        return 0.5 * (bmx::betabinom_pmf(c, n, a, b1) + bmx::betabinom_pmf(c, n, a, b2));
-    };
-    double base = 1. - np_sum_gen(nex, excl);
-    double psel = raw / base;
-    size_t o = ((size_t)ix * P.nab + ia) * P.rows + r;
-    double R = psel * P.prop[j] / P.g[r] - 1.0;
+        else c = n - m + 1 + (it - m);
+        const int nfold = (site && maf) ? 2 : 1;                  // pmf(k) + pmf(n-k)  (v1:389)
+        double v[2];
+        for (int side = 0; side < 2; ++side) {
+            const double b = side ? b2 : b1;
+            double pr = 0.;
+            for (int f = 0; f < nfold; ++f) {
+                const double q = bmx::betabinom_pmf(f ? n - c : c, n, a, b);
+                pr = f ? pr + q : q;
+            }
+            if (site && maf && (n % 2 == 0) && c == n / 2) pr = pr / 2;      // v1:391-392
+            if (site && stat == BMX_STAT_B1) pr = (k == 0) ? pr : (1. - pr - pr);
+            v[side] = pr;
+        }
+        const double e = 0.5 * (v[0] + v[1]);
+        if (site) {
+            raw = e;
+        } else if (nex < 8) {
+            res += e;
+        } else if (it < nblk) {
+            if (it < 8) r8[it] = e; else r8[it & 7] += e;
+            if (it == nblk - 1)
+                res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+        } else {
+            res += e;
+        }
+    }
+    const double base = 1. - res;
+    const double psel = raw / base;
+    const size_t o = ((size_t)ix * P.nab + ia) * P.rows + r;
+    const double R = psel * P.prop[j] / P.g[r] - 1.0;
     P.psel[o] = psel;
     P.R[o] = R;
     P.Rt[(size_t)r * P.NP + p] = R;
@@ -411,6 +430,7 @@ int bmx_ctx_create(bmx_ctx **out, int device) {
     int n = bmx_device_count();
     if (n <= 0) return fail(BMX_E_NODEVICE, "no HIP device available (libbmxscan has no CPU fallback)");
     if (device < 0 || device >= n) return fail(BMX_E_NODEVICE, "device index out of range");
+    TRACE("ctx_create: hipSetDevice(%d)", device);
     HIP_TRY(hipSetDevice(device));
     bmx_ctx *c = new bmx_ctx();
     c->device = device;
@@ -420,6 +440,7 @@ int bmx_ctx_create(bmx_ctx **out, int device) {
         delete c;
         return fail(BMX_E_HIP, "stream/event creation failed");
     }
+    TRACE("ctx_create: done");
     *out = c;
     return BMX_OK;
 }
@@ -478,6 +499,7 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     P.x = c->d_x; P.abeta = c->d_abeta; P.psel = c->d_psel; P.R = c->d_R; P.Rt = c->d_Rt;
     int threads = 128;
     int blocks = (int)((tab + threads - 1) / threads);
+    TRACE("set_model: launching bb_lut_kernel, %d blocks x %d, rows=%d pairs=%d", blocks, threads, c->rows, c->npairs);
     hipLaunchKernelGGL(bb_lut_kernel, dim3(blocks), dim3(threads), 0, c->stream, P);
     HIP_TRY(hipGetLastError());
     // How many sites may be multiplied between exponent extractions: every factor
@@ -485,6 +507,7 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     std::vector<double> hR(tab);
     HIP_TRY(hipMemcpyAsync(hR.data(), c->d_R, tab * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    TRACE("set_model: table built");
     double span = 60.0;  // alpha -> 1 with R = -1: factor 1 - alpha >= ~2^-53
     for (size_t i = 0; i < tab; i++) {
         double v = hR[i];
@@ -568,6 +591,7 @@ int bmx_ctx_scan(bmx_ctx *c) {
     if (blocks > 0x7fffffffLL) return fail(BMX_E_LIMIT, "too many workgroups; split the test sites");
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
     bool use_lds = lds <= (size_t)LDS_LIMIT_BYTES && c->variant != 1;
+    TRACE("scan: %lld blocks, lds=%zu use_lds=%d renorm_every=%d spb=%d", (long long)blocks, lds, (int)use_lds, c->renorm_every, P.sites_per_block);
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (use_lds) {
         HIP_TRY(hipFuncSetAttribute((const void *)clr_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

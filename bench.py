@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- CLR windows/s of the B_2 scan (BASELINE.json metric) on N MI355X.
+
+One step = one pass of the hot path over one batch: every SNP of a synthetic 1M-SNP, n=100
+chromosome is a test site and gets the full default (A, x, alpha_beta) grid search
+(BASELINE config 3; at N>1 every rank scans its own chromosome of the same size = weak scaling,
+the shape of config 4, followed by the RCCL all-gather of the result records).  Inputs are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--snps 1000000] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6300 achievable)
+FLOP_PER_EVAL = 3                # executed per (site, grid pair): 1 FMA (2 flop) + 1 MUL
+SURVEY_FLOP_PER_EVAL = 32        # SURVEY.md 8(d) convention for the reference's FMA + log1p form
+
+
+def window_work(gen, As, zcut, test_idx):
+    """sum_A W_A(t) per test site (sites with A*|g_i - t| <= zcut, ties with t excluded) and the
+    widest window W_max(t) (A_min) -- the algorithmic work / bytes of SURVEY.md 8(d)."""
+    t = gen[test_idx]
+    tot = np.zeros(len(t), dtype=np.int64)
+    wmax = np.zeros(len(t), dtype=np.int64)
+    ties = np.searchsorted(gen, t, 'right') - np.searchsorted(gen, t, 'left')
+    for A in As:
+        r = zcut / float(A)
+        w = np.searchsorted(gen, t + r, 'right') - np.searchsorted(gen, t - r, 'left') - ties
+        w = np.maximum(w, 0)
+        tot += w
+        wmax = np.maximum(wmax, w)
+    return tot, wmax
+
+
+def cpu_baseline(gen, k, nn, spect, props, grid, n_windows_faithful, n_windows_c):
+    """Times the ORACLE on this box's host cores (reported baseline, never the product path)."""
+    from oracle import bmx_oracle as orc
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from util import c_oracle, c_scan
+    xs, ab, As = grid.scan_order()
+    N = len(gen)
+    t0 = time.time()
+    m = orc.Model('B2', gen, k, nn, spect, props, int(k.min()), xs, ab, As)
+    # same arithmetic as the reference per window; P_sel gathered from the (k,n) table instead
+    # of from 510 materialised N-length arrays (4 GB at N = 1M)
+    m._norm_probs = _LazyNorm(m)
+    t_init = time.time() - t0
+    idx = np.linspace(0, N - 1, n_windows_faithful + 2).astype(int)[1:-1]
+    t0 = time.time()
+    for i in idx:
+        orc.calc_baller_faithful(m, 0, N - 1, gen[i])
+    dt = time.time() - t0
+    out = {'value': len(idx) / dt, 'unit': 'windows/s', 'cores': 1, 'kind': 'port',
+           'sample': '%d windows evenly spaced over the %d-SNP chromosome, oracle/bmx_oracle.py '
+                     'calc_baller_faithful (numpy, same per-A masks and per-(x,a) sums as '
+                     'BalLeRMix+_v1.py:453-505), %.1f s; table init %.1f s' % (len(idx), N, dt, t_init)}
+    # optimised C restatement on all cores, for scale
+    try:
+        L = c_oracle()
+        cores = os.cpu_count() or 1
+        idx = np.linspace(0, N - 1, n_windows_c + 2).astype(int)[1:-1]
+        t0 = time.time()
+        c_scan(L, m.R, As, gen, m.row, gen[idx], np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64))
+        dt = time.time() - t0
+        out['c_port'] = {'value': len(idx) / dt, 'unit': 'windows/s', 'cores': cores,
+                         'sample': '%d windows, oracle/bmx_oracle.c orc_scan (log1p/LUT form, OpenMP), %.1f s' % (len(idx), dt)}
+    except Exception as e:  # the C leg is optional
+        out['c_port'] = {'error': str(e)}
+    return out
+
+
+class _LazyNorm(dict):
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def __missing__(self, key):
+        ix, ia = key
+        return _Gather(self.m.psel[ix, ia], self.m.row)
+
+
+class _Gather:
+    """normProbs[(x,a)][subwindow] == psel[x,a][row[subwindow]]"""
+
+    def __init__(self, tab, row):
+        self.tab, self.row = tab, row
+
+    def __getitem__(self, sub):
+        return self.tab[self.row[sub]]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--snps', type=int, default=1000000, help='SNPs (= windows) per GPU per step')
+    ap.add_argument('--n', type=int, default=100)
+    ap.add_argument('--variant', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-windows', type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    from ballermixplus_amd import distributed, engine, synth
+    from ballermixplus_amd.hostmodel import Grids
+
+    world = distributed.World.from_env()
+    if world.size != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world.size, args.gpus))
+    rank, dev = world.rank, world.local_rank
+    torch.cuda.set_device(dev)
+
+    N, n = args.snps, args.n
+    phys, gen, k, nn = synth.synth_chromosome(N, n, chrom=rank + 1)
+    spect = {(a, b): f for a, b, f in synth.spect_from_counts(k, nn)}
+    props = {n: 1.0}
+    grid = Grids(None, None, False, False, None, None)
+    xs, ab, As = grid.scan_order()
+    model = engine.ModelArrays('B2', int(k.min()), [n], spect, props, xs, ab)
+    ctx = engine.Context(dev)
+    ctx.set_variant(args.variant)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, model.rows_of(k, nn))
+    ctx.set_tests(gen, np.zeros(N, np.int64), np.full(N, N - 1, np.int64))     # resident in HBM from here on
+
+    from ballermixplus_amd import _lib
+    zcut = _lib.lib().bmx_alpha_cut()
+    wsum, wmax = window_work(gen, As, zcut, np.arange(N))
+    evals_per_step = float(wsum.sum()) * len(xs) * len(ab)
+    bytes_per_step = float(wmax.sum()) * 10.0 + 24.0 * N      # W_max*10 B + 24 B per window
+
+    def gather():
+        if world.size > 1:
+            pc, pl, pn = ctx.result_ptrs()
+            d = torch.device('cuda', dev)
+            clr = torch.as_tensor(distributed._DevArray(pc, N, '<f8'), device=d)
+            lin = torch.as_tensor(distributed._DevArray(pl, N, '<i4'), device=d)
+            ns = torch.as_tensor(distributed._DevArray(pn, N, '<i4'), device=d)
+            outs = []
+            for t in (clr, lin, ns):
+                buf = torch.empty(N * world.size, dtype=t.dtype, device=d)
+                torch.distributed.all_gather_into_tensor(buf, t)
+                outs.append(buf)
+            return outs
+        return None
+
+    def barrier():
+        if world.size > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.scan()
+        ctx.sync()
+        gather()
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.scan()
+        ctx.sync()                       # results must be complete before the gather reads them
+        kernel_ms.append(ctx.last_scan_ms())
+        gather()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world.size > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device('cuda', dev))
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    clr, ix, ia, iA, ns = ctx.fetch()
+    checksum = float(np.sum(clr))
+
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        windows = float(N) * world.size * args.steps
+        evals_s = evals_per_step / (k_ms * 1e-3)
+        res = {
+            'metric': 'CLR windows/sec (B2 scan, n=%d)' % n,
+            'value': windows / dt,
+            'unit': 'windows/s',
+            'n_gpus': world.size, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE config 3: synthetic single chromosome, %d SNPs, n=%d, default '
+                                   '31x10x51 (A,x,alpha) grid, B2 scan, every SNP a test site; one chromosome '
+                                   'per GPU' % (N, n),
+                       'windows_per_step_per_gpu': N, 'grid_points': len(As) * len(xs) * len(ab),
+                       'parallelism': 'test-site sharding, dp%d, RCCL all_gather of 16-B records per step' % world.size,
+                       'checksum_clr_rank0': checksum},
+            'roofline': {
+                'bound': 'valu_fp64', 'kernel': 'clr_scan_kernel',
+                'achieved': evals_s * FLOP_PER_EVAL / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': evals_s * FLOP_PER_EVAL / 1e12 / FP64_VALU_PEAK_TFLOPS, 'traffic': None,
+                'kernel_ms': k_ms, 'evals_per_launch': evals_per_step, 'evals_per_s': evals_s,
+                'flop_per_eval_executed': FLOP_PER_EVAL,
+                'survey_convention_tflops': evals_s * SURVEY_FLOP_PER_EVAL / 1e12,
+                'note': 'lanes multiply (1+alpha*R) instead of summing log1p: 1 FMA + 1 MUL per evaluation; '
+                        'peak = vector FP64 (not MFMA: no contraction exists in this path)'},
+            'roofline_hbm': {
+                'bound': 'hbm', 'kernel': 'clr_scan_kernel',
+                'achieved': bytes_per_step / (k_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': bytes_per_step / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                'algorithmic_bytes_per_launch': bytes_per_step},
+        }
+        if not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(gen, k, nn, spect, props, grid, args.cpu_windows, 256)
+        print(json.dumps(res))
+    ctx.close()
+    world.finish()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,235 @@
+"""GPU parity: the HIP path, called through the C ABI, against the reference's goldens and
+the oracle.  Tolerances: integer/index fields exact (ties within rounding noise excepted, see
+cases.compare_rows); CLR within 1e-6 relative (BASELINE.json north_star), absolute floor 1e-9."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from util import GOLD, c_oracle, c_scan, orc, read_tsv
+
+pytestmark = pytest.mark.gpu
+
+LUTS = sorted(glob.glob(os.path.join(GOLD, 'lut_*.npz')))
+
+
+def _engine():
+    from ballermixplus_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize('path', LUTS, ids=[os.path.basename(p)[4:-4] for p in LUTS])
+def test_device_selection_table_matches_reference(path):
+    """K1 (device lgamma / beta-binomial) vs NormalizedBetaBinom.normProbs of the reference."""
+    eng = _engine()
+    stat = os.path.basename(path)[4:-4].split('_')[0]
+    z = np.load(path)
+    xs, ab, minc = z['x'].tolist(), z['abeta'].tolist(), int(z['minCount'])
+    sizes = sorted(set(z['total'].tolist()))
+    spect = {(k, n): 1.0 for n in sizes for k in range(n + 1)}
+    props = {n: 1.0 for n in sizes}
+    model = eng.ModelArrays(stat, minc, sizes, spect, props, xs, ab)
+    ctx = eng.Context(0)
+    ctx.set_model(model, [100.0])
+    psel, R = ctx.fetch_lut()
+    rows = model.rows_of(z['count'], z['total'])
+    got = psel[:, :, rows]
+    ref = z['table']
+    rel = np.abs(got - ref) / np.abs(ref)
+    # The large-argument lgam noise (alpha_beta >= 1e4) must be REPRODUCED, not merely
+    # approximated: a 1-ulp-accurate log would already be off by 1e-5 at alpha_beta = 1e9.
+    # The device log is correctly rounded; glibc's (which scipy calls) is not on ~0.015 % of
+    # the arguments, and one such argument (x ~ 1e4, n = 200 table) moves one entry by 1.5e-11.
+    assert np.nanmax(rel) < 1e-9, float(np.nanmax(rel))
+    assert np.mean(rel[np.isfinite(rel)] > 1e-13) < 1e-3
+    assert np.allclose(R[:, :, rows], got - 1.0, rtol=0, atol=1e-15 * np.abs(got).max() + 1e-300)
+    ctx.close()
+
+
+def _run_case(name):
+    eng = _engine()
+    from ballermixplus_amd import scan as scanmod
+    argv, gold = cases.ALL_CASES[name]
+    opt, case, ts = cases.host_side(argv)
+    sel = eng.NormalizedBetaBinom(case.data, case.grid, opt.nofreq, opt.MAF, opt.nosub)
+    sel.bind(case.neut)
+    res = eng.scan_batch(sel, ts.test_gen, ts.lo, ts.hi)
+    out = '/tmp/bmx_gpu_%s.tsv' % name
+    scanmod.write_rows(out, ts, res, sel)
+    with open(out) as f:
+        lines = f.readlines()[1:]
+    return case, ts, lines, gold
+
+
+@pytest.mark.parametrize('name', sorted(cases.ALL_CASES))
+def test_scan_reproduces_golden_file(name):
+    """Every row of every golden output file (configs 1 and 2 of BASELINE.json among them)."""
+    if not os.path.exists(cases.ALL_CASES[name][1]):
+        pytest.skip('fixture not generated')
+    case, ts, lines, gold = _run_case(name)
+    worst, ties = cases.compare_rows(lines, gold, rtol=1e-6, case=case, ts=ts)
+    assert worst < 1e-6
+    assert ties == 0 or name.endswith('B1'), ties
+
+
+def test_cli_end_to_end_config1(tmp_path):
+    """The drop-in command line itself, byte-compatible header and row format."""
+    from ballermixplus_amd import cli
+    argv, gold = cases.ALL_CASES['ex1_B2']
+    out = tmp_path / 'o.txt'
+    cli.main(argv + ['-o', str(out), '-s', '50'])
+    got = out.read_text().splitlines()
+    assert got[0] == 'physPos\tgenPos\tCLR\tx_hat\ts_hat\tA_hat\tnSites'
+    ref = read_tsv(gold)[::50]
+    for a, b in zip([l.split('\t') for l in got[1:]], ref):
+        assert a[:2] == b[:2] and a[3:] == b[3:]
+        assert abs(float(a[2]) - float(b[2])) <= 1e-6 * abs(float(b[2]))
+
+
+def _synth_case(N, n, chrom=1, bal=False, listA=None):
+    from ballermixplus_amd import synth
+    from ballermixplus_amd.hostmodel import Grids
+    phys, gen, k, nn = synth.synth_chromosome(N, n, chrom)
+    spect = {(a, b): f for a, b, f in synth.spect_from_counts(k, nn)}
+    props = {n: 1.0}
+    grid = Grids(None, None, bal, bal, None, listA)
+    return phys, gen, k, nn, spect, props, grid
+
+
+@pytest.mark.parametrize('key,N,n,step,bal', [('20k', 20000, 100, 200, False), ('20k_n200_bal', 20000, 200, 400, True),
+                                              ('1M', 1000000, 100, 100000, False)])
+def test_synthetic_strided_windows_match_reference(key, N, n, step, bal):
+    """BASELINE configs 3/5 in miniature + config 3 at full size on the windows the reference
+    could afford (tests/golden/synth, produced by running the reference with -s)."""
+    path = os.path.join(GOLD, 'synth', 'synth_%s_step%d.tsv' % (key, step))
+    if not os.path.exists(path):
+        pytest.skip('fixture not generated')
+    eng = _engine()
+    listA = ','.join(str(100 * i) for i in range(1, 101)) if bal else None
+    phys, gen, k, nn, spect, props, grid = _synth_case(N, n, 2 if bal else 1, bal, listA)
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays('B2', int(k.min()), [n], spect, props, xs, ab)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, model.rows_of(k, nn))
+    idx = np.arange(0, N, step)
+    ctx.set_tests(gen[idx], np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64))
+    ctx.scan()
+    clr, ix, ia, iA, ns = ctx.fetch()
+    rows = read_tsv(path)
+    assert len(rows) == len(idx)
+    for j, r in enumerate(rows):
+        assert int(r[0]) == phys[idx[j]]
+        if r[3:6] == ['0.0', '0.0', '0.0']:
+            assert iA[j] < 0
+            continue
+        assert (repr(xs[ix[j]]), repr(ab[ia[j]]), repr(As[iA[j]]), str(ns[j])) == (r[3], r[4], r[5], r[6]), (j, r)
+        assert abs(clr[j] - float(r[2])) <= max(1e-9, 1e-6 * abs(float(r[2]))), (j, r, clr[j])
+    ctx.close()
+
+
+def test_full_size_properties_config3():
+    """Config 3 (1M SNPs, n=100, default grid) at full size, through properties that need no
+    reference run: (i) a strided subset scanned alone equals the same rows of a denser scan
+    (shard invariance: what multi-GPU sharding relies on); (ii) windows fully inside a 60k-site
+    sub-chromosome give bit-identical rows when that sub-chromosome is scanned on its own;
+    (iii) the C oracle agrees on a sample of rows."""
+    eng = _engine()
+    N, n = 1000000, 100
+    phys, gen, k, nn, spect, props, grid = _synth_case(N, n)
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays('B2', int(k.min()), [n], spect, props, xs, ab)
+    rows = model.rows_of(k, nn)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, rows)
+    full_lo = lambda m: np.zeros(m, np.int64)
+    idx = np.arange(400000, 400000 + 8192)
+    ctx.set_tests(gen[idx], full_lo(len(idx)), np.full(len(idx), N - 1, np.int64))
+    ctx.scan()
+    dense = [a.copy() for a in ctx.fetch()]
+    sub = idx[::7]
+    ctx.set_tests(gen[sub], full_lo(len(sub)), np.full(len(sub), N - 1, np.int64))
+    ctx.scan()
+    sparse = ctx.fetch()
+    for a, b in zip(dense, sparse):
+        assert np.array_equal(a[::7], b)
+    # (ii) cut out [370000, 440000): all windows of idx (+-2.6k sites) lie inside
+    lo_c, hi_c = 370000, 440000
+    ctx2 = eng.Context(0)
+    ctx2.set_model(model, As)
+    ctx2.set_sites(gen[lo_c:hi_c], rows[lo_c:hi_c])
+    ctx2.set_tests(gen[idx], full_lo(len(idx)), np.full(len(idx), hi_c - lo_c - 1, np.int64))
+    ctx2.scan()
+    cut = ctx2.fetch()
+    for a, b in zip(dense, cut):
+        assert np.array_equal(a, b)
+    # (iii) oracle on 24 rows
+    L = c_oracle()
+    _, R = ctx.fetch_lut()
+    pick = idx[:: len(idx) // 24][:24]
+    oc = c_scan(L, R, As, gen[lo_c:hi_c], rows[lo_c:hi_c], gen[pick], np.zeros(len(pick), np.int64),
+                np.full(len(pick), hi_c - lo_c - 1, np.int64))
+    sel = np.searchsorted(idx, pick)
+    assert np.array_equal(oc[1], dense[1][sel]) and np.array_equal(oc[2], dense[2][sel])
+    assert np.array_equal(oc[3], dense[3][sel]) and np.array_equal(oc[4], dense[4][sel])
+    assert np.max(np.abs(oc[0] - dense[0][sel]) / np.maximum(np.abs(oc[0]), 1e-9)) < 1e-9
+    ctx.close()
+    ctx2.close()
+
+
+def test_edge_cases():
+    """Empty windows, a single site, duplicated positions (all ties excluded, v1:455), windows
+    that exclude the test site's neighbourhood, and a test position off the site grid."""
+    eng = _engine()
+    L = c_oracle()
+    n = 20
+    rng = np.random.default_rng(5)
+    N = 300
+    gen = np.sort(np.round(rng.uniform(0, 0.02, N), 5))      # rounding creates exact ties
+    k = rng.integers(1, n + 1, N)
+    nn = np.full(N, n)
+    from ballermixplus_amd import synth
+    from ballermixplus_amd.hostmodel import Grids
+    spect = {(a, b): f for a, b, f in synth.spect_from_counts(np.concatenate([k, np.arange(1, n + 1)]),
+                                                               np.full(N + n, n))}
+    grid = Grids(None, None, False, False, None, None)
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays('B2', 1, [n], spect, {n: 1.0}, xs, ab)
+    rows = model.rows_of(k, nn)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, rows)
+    tg = np.concatenate([gen[:40], [gen[0] - 1.0, gen[-1] + 1.0, 0.5 * (gen[10] + gen[11])], gen[100:110]])
+    lo = np.concatenate([np.zeros(40, np.int64), [0, 0, 0], np.arange(100, 110) + 5]).astype(np.int64)
+    hi = np.concatenate([np.full(40, N - 1), [N - 1, N - 1, N - 1], np.arange(100, 110) + 4]).astype(np.int64)
+    hi[:5] = [0, 1, 2, 3, 4]          # tiny windows at the left edge
+    ctx.set_tests(tg, lo, hi)
+    ctx.scan()
+    got = ctx.fetch()
+    _, R = ctx.fetch_lut()
+    ref = c_scan(L, R, As, gen, rows, tg, lo, hi)
+    assert np.array_equal(got[4], ref[4])
+    for f in (1, 2, 3):
+        assert np.array_equal(got[f], ref[f])
+    assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-12)
+    assert np.all(got[3][43:] == -1) and np.all(got[0][43:] == 0)      # lo > hi: empty windows
+    ctx.close()
+
+
+def test_abi_error_paths():
+    from ballermixplus_amd import _lib, engine
+    ctx = engine.Context(0)
+    with pytest.raises(_lib.BmxError):
+        ctx.scan()                                   # nothing set yet
+    model = engine.ModelArrays('B2', 1, [10], {(k, 10): 0.1 for k in range(11)}, {10: 1.0}, [0.5], [1.0])
+    ctx.set_model(model, [100.0])
+    with pytest.raises(_lib.BmxError):
+        ctx.set_sites([0.2, 0.1], [1, 2])            # unsorted positions
+    with pytest.raises(_lib.BmxError):
+        ctx.set_sites([0.1, 0.2], [1, 99])           # row outside the table
+    with pytest.raises(_lib.BmxError):
+        engine.Context(999)
+    ctx.close()
