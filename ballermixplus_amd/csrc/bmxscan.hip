@@ -318,9 +318,20 @@ struct GroupMeta {
     int lo, hi;  // its inclusive window, empty (1,0) for j beyond the last test site
 };
 
-template <int J, bool USE_LDS>
+// MODE 0: (E_i, row_i) and alpha_ij reach the lanes by v_readlane, one site per step.
+// MODE 1: they are staged in a wave-private LDS scratch and read back with uniform-address
+//         (broadcast) ds_read_b128, and bulk sites are taken two at a time:
+//             (1 + F v1)(1 + F v2) = 1 + F*(s + F*q),   s = v1 + v2,  q = v1*v2
+//         i.e. 2 FMA + 1 MUL per test site per PAIR of sites (s, q shared by all J test sites).
+struct alignas(16) ScratchEnt {
+    double e;
+    int ro;   // row * 64
+    int pad;
+};
+
+template <int J, bool USE_LDS, int MODE>
 __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanParams P) {
-    extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS
+    extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then scratch
     constexpr int SP = WAVE / J;                                    // sites per generic pass
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x >> 6;
@@ -340,6 +351,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanPara
     auto loadR = [&](int rowoff) -> double {                       // rowoff = row * 64
         return USE_LDS ? lds_R[rowoff + lane] : Rg[(size_t)(rowoff >> 6) * P.NP];
     };
+    // wave-private scratch behind the R slice: 64 x 16 B
+    ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_R + (USE_LDS ? P.rows * WAVE : 0)) + wave * WAVE;
+    double *scr_d = reinterpret_cast<double *>(scr);
 
     const int64_t ngroups = (P.M + J - 1) / J;
     const int64_t gpb = P.sites_per_block / J;
@@ -403,13 +417,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanPara
                     const double alpha = in ? exp(-z) : 0.0;
                     const int rowoff = inr ? (int)P.row[i] * WAVE : 0;
                     spend(SP * span_generic);
+                    if (MODE == 1) {
+                        scr_d[lane] = alpha;
+                        __builtin_amdgcn_wave_barrier();
+                    }
 #pragma unroll
                     for (int s = 0; s < SP; ++s) {
                         if (((m_in >> (s * J)) & ((1ull << J) - 1ull)) == 0ull) continue;
                         const double R = loadR(__builtin_amdgcn_readlane(rowoff, s * J));
+                        if (MODE == 1) {
+                            const double2 *a2 = reinterpret_cast<const double2 *>(scr_d + s * J);
 #pragma unroll
-                        for (int j = 0; j < J; ++j) acc[j] *= fma(readlane_f64(alpha, s * J + j), R, 1.0);
+                            for (int j = 0; j < J; j += 2) {
+                                const double2 a = a2[j >> 1];              // uniform address: LDS broadcast
+                                acc[j] *= fma(a.x, R, 1.0);
+                                acc[j + 1] *= fma(a.y, R, 1.0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < J; ++j) acc[j] *= fma(readlane_f64(alpha, s * J + j), R, 1.0);
+                        }
                     }
+                    if (MODE == 1) __builtin_amdgcn_wave_barrier();
                 }
                 return __ballot(fin) == ~0ull;
             };
@@ -439,14 +468,35 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanPara
                         const double om = 1.0 - readlane_f64(Ev, 0);
                         const int lowbits = 1024 - ((__double2hiint(om) >> 20) & 0x7ff);
                         const int span8 = 8 * min(max(P.span_hi, lowbits), 125);
-                        for (int l0 = 0; l0 < cnt; l0 += 8) {
-                            spend(span8);
+                        if (MODE == 1) {
+                            scr[lane] = ScratchEnt{Ev, rowoff, 0};
+                            __builtin_amdgcn_wave_barrier();
+                            for (int l0 = 0; l0 < cnt; l0 += 8) {
+                                spend(span8);
+                                double v[8];
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                const int l = l0 + u;               // lanes >= cnt carry Ev = 0: factor 1
-                                const double v = readlane_f64(Ev, l) * loadR(__builtin_amdgcn_readlane(rowoff, l));
+                                for (int u = 0; u < 8; ++u) {       // lanes >= cnt carry Ev = 0: factor 1
+                                    const ScratchEnt en = scr[l0 + u];     // uniform address: LDS broadcast
+                                    v[u] = en.e * loadR(en.ro);
+                                }
 #pragma unroll
-                                for (int j = 0; j < J; ++j) acc[j] *= fma(F[j], v, 1.0);
+                                for (int u = 0; u < 8; u += 2) {
+                                    const double sv = v[u] + v[u + 1], qv = v[u] * v[u + 1];
+#pragma unroll
+                                    for (int j = 0; j < J; ++j) acc[j] *= fma(F[j], fma(F[j], qv, sv), 1.0);
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        } else {
+                            for (int l0 = 0; l0 < cnt; l0 += 8) {
+                                spend(span8);
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const int l = l0 + u;           // lanes >= cnt carry Ev = 0: factor 1
+                                    const double v = readlane_f64(Ev, l) * loadR(__builtin_amdgcn_readlane(rowoff, l));
+#pragma unroll
+                                    for (int j = 0; j < J; ++j) acc[j] *= fma(F[j], v, 1.0);
+                                }
                             }
                         }
                     }
@@ -835,13 +885,17 @@ int bmx_ctx_scan(bmx_ctx *c) {
     P.A = c->d_A; P.nA = c->nA; P.test_gen = c->d_test_gen; P.win_lo = c->d_win_lo; P.win_hi = c->d_win_hi;
     P.center = c->d_center; P.center_hi = c->d_center_hi; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi;
     P.part_T = c->d_part_T; P.part_lin = c->d_part_lin; P.part_ns = c->d_part_ns;
-    // variant 0: grouped kernel (J = 8) when it applies; 1: per-site kernel reading R from global;
-    // 2: per-site kernel (LDS); 3: grouped J = 16; 4: grouped J = 4
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
-    const bool fits = lds <= (size_t)LDS_LIMIT_BYTES;
+    if (const char *pad = getenv("BMX_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
+    const bool fits = lds + (size_t)SCAN_THREADS * sizeof(ScratchEnt) <= (size_t)LDS_LIMIT_BYTES;
     const bool can_group = c->tests_sorted && c->span_hi <= 62 && c->N < 0x7fffffffLL;
     int J = 0;
-    if (can_group) J = c->variant == 0 ? 8 : c->variant == 3 ? 16 : c->variant == 4 ? 4 : 0;
+    // variants: 0 -> J=16 pair/LDS-broadcast (default); 3 -> J=8, 4 -> J=4 (same mode);
+    //           5/6/7 -> J=16/8/4 with the readlane single-site inner loop; 1, 2 -> per-site kernel
+    if (can_group) {
+        const int v = c->variant;
+        J = (v == 0 || v == 5) ? 16 : (v == 3 || v == 6) ? 8 : (v == 4 || v == 7) ? 4 : 0;
+    }
     P.sites_per_block = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : 4);
     if (J == 16 && P.sites_per_block < 64) P.sites_per_block = 64;
     int64_t chunks = (c->M + P.sites_per_block - 1) / P.sites_per_block;
@@ -852,14 +906,20 @@ int bmx_ctx_scan(bmx_ctx *c) {
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     const void *fn = nullptr;
 #define PICK(K) (use_lds ? (const void *)K<true> : (const void *)K<false>)
-    if (J == 8) fn = use_lds ? (const void *)clr_scan_grouped_kernel<8, true> : (const void *)clr_scan_grouped_kernel<8, false>;
-    else if (J == 16) fn = use_lds ? (const void *)clr_scan_grouped_kernel<16, true> : (const void *)clr_scan_grouped_kernel<16, false>;
-    else if (J == 4) fn = use_lds ? (const void *)clr_scan_grouped_kernel<4, true> : (const void *)clr_scan_grouped_kernel<4, false>;
+    const int mode = (c->variant >= 5 && c->variant <= 7) ? 0 : 1;
+#define GPICK(JJ) (mode ? (use_lds ? (const void *)clr_scan_grouped_kernel<JJ, true, 1> : (const void *)clr_scan_grouped_kernel<JJ, false, 1>) \
+                        : (use_lds ? (const void *)clr_scan_grouped_kernel<JJ, true, 0> : (const void *)clr_scan_grouped_kernel<JJ, false, 0>))
+    if (J == 8) fn = GPICK(8);
+    else if (J == 16) fn = GPICK(16);
+    else if (J == 4) fn = GPICK(4);
     else fn = PICK(clr_scan_kernel);
+#undef GPICK
 #undef PICK
-    if (use_lds) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    size_t lds_bytes = (use_lds ? lds : 0) + (J ? (size_t)SCAN_THREADS * sizeof(ScratchEnt) : 0);
+    if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return fail(BMX_E_LIMIT, "LDS budget exceeded");
+    if (lds_bytes) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     void *kargs[] = {&P};
-    HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(SCAN_THREADS), kargs, use_lds ? lds : 0, c->stream));
+    HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(SCAN_THREADS), kargs, lds_bytes, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     FinalParams F;
     F.part_T = c->d_part_T; F.part_lin = c->d_part_lin; F.part_ns = c->d_part_ns;
