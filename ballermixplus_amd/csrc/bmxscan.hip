@@ -890,11 +890,11 @@ int bmx_ctx_scan(bmx_ctx *c) {
     const bool fits = lds + (size_t)SCAN_THREADS * sizeof(ScratchEnt) <= (size_t)LDS_LIMIT_BYTES;
     const bool can_group = c->tests_sorted && c->span_hi <= 62 && c->N < 0x7fffffffLL;
     int J = 0;
-    // variants: 0 -> J=16 pair/LDS-broadcast (default); 3 -> J=8, 4 -> J=4 (same mode);
+    // variants: 0 -> J=8 pair/LDS-broadcast (default); 3 -> J=16, 4 -> J=4 (same mode);
     //           5/6/7 -> J=16/8/4 with the readlane single-site inner loop; 1, 2 -> per-site kernel
     if (can_group) {
         const int v = c->variant;
-        J = (v == 0 || v == 5) ? 16 : (v == 3 || v == 6) ? 8 : (v == 4 || v == 7) ? 4 : 0;
+        J = (v == 3 || v == 5) ? 16 : (v == 0 || v == 6) ? 8 : (v == 4 || v == 7) ? 4 : 0;
     }
     P.sites_per_block = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : 4);
     if (J == 16 && P.sites_per_block < 64) P.sites_per_block = 64;

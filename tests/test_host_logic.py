@@ -1,0 +1,123 @@
+"""Host-side mirror of the reference (no GPU): grids and their set() iteration order, input
+parsing, helper-file generation (byte-exact), window generation for the four Scan modes."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from util import GOLD, REFT, load_json, read_tsv
+
+from ballermixplus_amd import helpers
+from ballermixplus_amd.hostmodel import Grids, InputData, NeutralSFS
+
+
+def _r(v):
+    return [repr(x) for x in v]
+
+
+def test_grid_lists_and_iteration_order_match_reference():
+    so = load_json('setorder.json')
+    g = Grids(None, None, False, False, None, None)
+    assert _r(g.x) == so['default']['x_list'] and _r(g.abeta) == so['default']['abeta_list']
+    assert _r(g.A) == so['default']['A_list']
+    xs, ab, As = g.scan_order()
+    assert (_r(xs), _r(ab), _r(As)) == (so['default']['x'], so['default']['abeta'], so['default']['A'])
+    assert len(ab) == 51 and len(As) == 31                      # the duplicated 5 collapses (v1:157)
+    g = Grids(None, None, True, False, None, None)
+    xs, ab, As = g.scan_order()
+    assert (_r(xs), _r(ab), _r(As)) == (so['bal']['x'], so['bal']['abeta'], so['bal']['A'])
+    g = Grids(None, None, True, True, None, so['config5']['listA'])   # --findBal wins over --findPos
+    xs, ab, As = g.scan_order()
+    assert (_r(xs), _r(ab), _r(As)) == (so['config5']['x'], so['config5']['abeta'], so['config5']['A'])
+    g = Grids('0.3', 7.0, False, False, None, '250,1e3,77.5')
+    xs, ab, As = g.scan_order()
+    assert (_r(xs), _r(ab), _r(As)) == (so['fixed']['x'], so['fixed']['abeta'], so['fixed']['A'])
+
+
+def test_rangeA_implements_the_evident_intent():
+    """The reference raises on --rangeA (float range + typo, v1:169-171); ours yields the
+    float grid Amin, Amin+step, ..., Amax -- the same values --listA gives (config 5)."""
+    g = Grids(None, None, True, True, '100,10000,100', None)
+    assert g.A == [float(100 * i) for i in range(1, 101)]
+
+
+@pytest.mark.parametrize('out,inp,kw', [
+    ('spect_ex1_DAF.txt', 'Example1_fullSweep_200kya_DAF.txt', dict(MAF=False, nosub=False)),
+    ('spect_ex1_MAFfold.txt', 'Example1_fullSweep_200kya_DAF.txt', dict(MAF=True, nosub=False)),
+    ('spect_ex2_MAF.txt', 'Example2_balancing_10MYA_MAF.txt', dict(MAF=True, nosub=False)),
+    ('spect_ex2_DAF_nosub.txt', 'Example2_balancing_10MYA_DAF.txt', dict(MAF=False, nosub=True)),
+    ('spect_ex2_MAF_nosub.txt', 'Example2_balancing_10MYA_MAF.txt', dict(MAF=True, nosub=True)),
+])
+def test_getSpect_is_byte_identical(tmp_path, out, inp, kw):
+    dst = tmp_path / out
+    helpers.getSpect(os.path.join(REFT, inp), str(dst), kw['MAF'], kw['nosub'])
+    assert filecmp.cmp(str(dst), os.path.join(GOLD, 'helpers', out), shallow=False)
+
+
+@pytest.mark.parametrize('out,inp', [('config_ex1.txt', 'Example1_fullSweep_200kya_DAF.txt'),
+                                     ('config_ex2.txt', 'Example2_balancing_10MYA_DAF.txt')])
+def test_getConfig_is_byte_identical(tmp_path, out, inp):
+    dst = tmp_path / out
+    helpers.getConfig(os.path.join(REFT, inp), str(dst))
+    assert filecmp.cmp(str(dst), os.path.join(GOLD, 'helpers', out), shallow=False)
+
+
+def test_input_parsing_semantics():
+    d = InputData(os.path.join(REFT, 'Example1_fullSweep_200kya_DAF.txt'))
+    assert d.numSites == 757 and d.minCount == 1 and d.sampSizes == {50}
+    assert d.position[0] == 12 and d.genPos[0] == 1.2e-07 and d.count[0] == 50
+    m = InputData(os.path.join(REFT, 'Example1_fullSweep_200kya_DAF.txt'), MAF=True)
+    assert m.count.max() <= 25 and m.count[0] == 0 and m.minCount == 1      # folded, k=n -> 0
+    p = InputData(os.path.join(REFT, 'Example1_fullSweep_200kya_DAF.txt'), phys=True, Rrate=2e-6)
+    assert p.genPos[0] == 12.0 * 2e-6
+    ns = InputData(os.path.join(REFT, 'Example2_balancing_10MYA_DAF.txt'), nosub=True)
+    assert np.all(ns.count != ns.total) and ns.numSites == len(ns.count) == 285
+    b1 = InputData(os.path.join(REFT, 'Example1_fullSweep_200kya_DAF.txt'), nofreq=True)
+    assert set(b1.count.tolist()) == {0, 1}
+
+
+def test_neutral_model_semantics():
+    n = NeutralSFS(os.path.join(REFT, 'HC_CEU_Neut_DAF_spect_for_B2.txt'), False, False, False)
+    assert len(n.spect) == 50 and abs(n.sampProps[50] - 1.0) < 1e-12
+    c = NeutralSFS(os.path.join(REFT, 'HC_CEU_Neut_config_for_B1.txt'), True, False, False)
+    assert c.spect == {(0, 50): 0.7237520358450141, (1, 50): 0.27624796415498587}
+    with pytest.raises(SystemExit):          # (k,n) not covered by the helper file (v1:281-287)
+        d = InputData(os.path.join(REFT, 'Example1_fullSweep_200kya_DAF.txt'))
+        NeutralSFS(os.path.join(REFT, 'HC_CEU_Neut_DAF-nosub_spect_for_B0.txt'), False, False, False).get_neut_probs(d)
+
+
+@pytest.mark.parametrize('name', sorted(cases.ALL_CASES))
+def test_window_generation_visits_the_reference_test_sites(name):
+    """Test positions, NA rows and their order must equal the golden file's first two columns."""
+    argv, gold = cases.ALL_CASES[name]
+    opt, case, ts = cases.host_side(argv)
+    rows = read_tsv(gold)
+    assert len(rows) == len(ts) + len(ts.na_rows)
+    from ballermixplus_amd import scan as scanmod
+    class S:
+        grid_x, grid_abeta, grid_A = case.xs, case.abetas, case.As
+    for j, p in enumerate(ts.order):
+        line = scanmod.format_row(ts.phys[j], ts.gen_label[j], 0.0, 0, 0, 0, 0, S).split('\t')
+        assert line[:2] == rows[p][:2]
+        assert 0 <= ts.lo[j] and ts.hi[j] <= case.data.numSites - 1
+    for p, l in ts.na_rows.items():
+        assert l.rstrip('\n').split('\t') == rows[p]
+
+
+def test_window_bounds_of_each_mode():
+    d = InputData(os.path.join(REFT, 'Example1_fullSweep_200kya_DAF.txt'))
+    from ballermixplus_amd import scan as scanmod
+    ts = scanmod.sites_site_based(d, 50, 25.0)            # -w 50 -s 25: r left, r+1 right (v1:588)
+    assert (ts.lo[0], ts.hi[0]) == (0, 51) and (ts.lo[4], ts.hi[4]) == (50, 151)
+    assert ts.hi[-1] == d.numSites - 1
+    ts = scanmod.sites_alpha(d, 20.0)
+    assert len(ts) == 38 and set(ts.lo) == {0} and set(ts.hi) == {756}
+    p = InputData(os.path.join(REFT, 'Example2_balancing_10MYA_DAF.txt'), phys=True)
+    ts = scanmod.sites_fix_center(p, 5000.0, 40.0)
+    for j in range(len(ts)):                               # window = sites within +-2.5 kb, end inclusive
+        i = 40 * j
+        lo, hi = ts.lo[j], ts.hi[j]
+        assert p.position[lo] >= p.position[i] - 2500 and (lo == 0 or p.position[lo - 1] < p.position[i] - 2500)
+        assert hi == len(p.position) - 1 or p.position[hi] >= min(p.position[i] + 2500, p.position[-1])
