@@ -23,7 +23,10 @@ sys.path.insert(0, REPO)
 
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6300 achievable)
-FLOP_PER_EVAL = 3                # executed per (site, grid pair): 1 FMA (2 flop) + 1 MUL
+# executed FP64 flop per evaluation (one site x one grid pair x one test site) in the default kernel:
+# bulk sites go two at a time, (1+F v1)(1+F v2) = 1 + F*(s + F*q): 2 FMA + 1 MUL = 5 flop per pair and
+# test site, plus v1, v2, s, q (4 flop) shared by the J = 8 test sites of a group: 2.5 + 4/16 = 2.75
+FLOP_PER_EVAL = 2.75
 SURVEY_FLOP_PER_EVAL = 32        # SURVEY.md 8(d) convention for the reference's FMA + log1p form
 
 
@@ -109,7 +112,7 @@ def main():
     ap.add_argument('--n', type=int, default=100)
     ap.add_argument('--variant', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-windows', type=int, default=8)
+    ap.add_argument('--cpu-windows', type=int, default=48)
     args = ap.parse_args()
 
     import torch
@@ -209,8 +212,9 @@ def main():
                 'kernel_ms': k_ms, 'evals_per_launch': evals_per_step, 'evals_per_s': evals_s,
                 'flop_per_eval_executed': FLOP_PER_EVAL,
                 'survey_convention_tflops': evals_s * SURVEY_FLOP_PER_EVAL / 1e12,
-                'note': 'lanes multiply (1+alpha*R) instead of summing log1p: 1 FMA + 1 MUL per evaluation; '
-                        'peak = vector FP64 (not MFMA: no contraction exists in this path)'},
+                'note': 'lanes multiply (1+alpha*R) instead of summing log1p, two sites per step: 2 FMA + 1 MUL '
+                        'per test site per pair of sites; peak = vector FP64 (no contraction exists in this path, '
+                        'so not MFMA); survey_convention = SURVEY 8(d) "1 evaluation = 32 flop"'},
             'roofline_hbm': {
                 'bound': 'hbm', 'kernel': 'clr_scan_kernel',
                 'achieved': bytes_per_step / (k_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
