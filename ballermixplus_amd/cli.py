@@ -85,7 +85,7 @@ def main(argv=None):
     say('\n \t A= ' + ', '.join([str(A) for A in grid.A]))
     Sel_Probs = engine.NormalizedBetaBinom(data, grid, opt.nofreq, opt.MAF, opt.nosub, device=device)
     say(("\n%s. Start computing likelihood raito..." % (datetime.now())))
-    runner = world.sharded_runner() if world.size > 1 else None
+    runner = world.sharded_runner() if world.distributed else None
     Scan(data, Neutral, Sel_Probs, grid, opt.outfile if world.rank == 0 else None, fixSize=opt.size, r=opt.w,
          s=opt.step, phys=opt.phys, noCenter=opt.noCenter, runner=runner)
     world.finish()

@@ -184,6 +184,7 @@ struct ScanParams {
     double zcut;       // alpha >= 1e-8  <=>  A*d <= zcut  (v1:455)
     int renorm_every;  // per-site kernel: sites between exponent extractions
     int span_hi;       // grouped kernel: bits by which one factor 1+alpha*R can exceed 1 (>= 1)
+    double rmax;       // max(0, largest finite R of the table)
     int sites_per_block;
     double *part_T;    // [M][nslices]
     int32_t *part_lin;
@@ -451,10 +452,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanPara
 #pragma unroll
                     for (int j = 0; j < J; ++j) F[j] = readlane_f64(fv, j);
                 }
+                // the site data of the NEXT pass is requested before this pass's arithmetic starts,
+                // so its L2 latency hides under ~4000 cycles of FP64 work
+                int i = base + dir * lane;
+                double g_nx = P.genpos[min(max(i, 0), N - 1)];
+                int r_nx = (int)P.row[min(max(i, 0), N - 1)];
                 while (true) {
-                    const int i = base + dir * lane;
                     const bool ok = dir > 0 ? (i <= hi_min) : (i >= lo_max);
-                    const double g = ok ? P.genpos[i] : 0.0;
+                    const double g = g_nx;
+                    const int rraw = r_nx;
+                    const int inx = i + dir * WAVE;
+                    g_nx = P.genpos[min(max(inx, 0), N - 1)];
+                    r_nx = (int)P.row[min(max(inx, 0), N - 1)];
                     const bool bulk = ok && (A * fabs(g - tfar) <= P.zcut);
                     const unsigned long long mb = __ballot(bulk);
                     const int cnt = __popcll(mb);
@@ -462,12 +471,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanPara
                         const double Ev = bulk ? exp(-(A * fabs(g - tnear))) : 0.0;
                         // lanes past the bulk prefix carry Ev = 0; give them lane 0's (valid, finite)
                         // row so that 0*R is 0 and not 0*NaN from a row absent in the helper file
-                        int rowoff = bulk ? (int)P.row[i] * WAVE : 0;
+                        int rowoff = rraw * WAVE;
                         rowoff = bulk ? rowoff : __builtin_amdgcn_readlane(rowoff, 0);
-                        // lane 0 is the site nearest to the test sites: largest alpha of the pass
-                        const double om = 1.0 - readlane_f64(Ev, 0);
+                        // lane 0 is the site nearest to the test sites: largest alpha of the pass.
+                        // Every factor of this pass lies in [1 - E0, 1 + E0*Rmax].
+                        const double e0 = readlane_f64(Ev, 0);
+                        const double om = 1.0 - e0, op = fma(e0, P.rmax, 1.0);
                         const int lowbits = 1024 - ((__double2hiint(om) >> 20) & 0x7ff);
-                        const int span8 = 8 * min(max(P.span_hi, lowbits), 125);
+                        const int hibits = ((__double2hiint(op) >> 20) & 0x7ff) - 1022;
+                        const int span8 = 8 * min(max(hibits, lowbits), 125);
                         if (MODE == 1) {
                             scr[lane] = ScratchEnt{Ev, rowoff, 0};
                             __builtin_amdgcn_wave_barrier();
@@ -502,6 +514,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanPara
                     }
                     base += dir * cnt;
                     if (cnt < WAVE) break;
+                    i = inx;
                 }
                 return base;
             };
@@ -628,6 +641,7 @@ struct bmx_ctx {
     bool has_model = false;
     int stat = 0, min_count = 1, n_sizes = 0, rows = 0, nx = 0, nab = 0, npairs = 0, NP = 0, nslices = 0, nA = 0;
     int renorm_every = 16, span_hi = 1;
+    double rmax = 0.0;
     int32_t *d_sizes = nullptr, *d_row_off = nullptr;
     double *d_g = nullptr, *d_prop = nullptr, *d_x = nullptr, *d_abeta = nullptr, *d_A = nullptr;
     double *d_psel = nullptr, *d_R = nullptr, *d_Rt = nullptr;
@@ -810,6 +824,7 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     }
     if (!(fmax < 1e300)) return fail(BMX_E_INVALID, "selection table overflows (a neutral probability g is 0 or tiny)");
     c->span_hi = std::max(1, (int)std::ceil(std::log2(fmax)));
+    c->rmax = fmax - 1.0;
     // per-site kernel: worst case per factor is max(span_hi, 54 bits for 1 - alpha) -- see the kernel
     c->renorm_every = std::max(1, std::min(16, 1000 / std::max(c->span_hi, 54)));
     c->has_model = true;
@@ -883,7 +898,7 @@ int bmx_ctx_scan(bmx_ctx *c) {
     P.genpos = c->d_genpos; P.row = c->d_row; P.N = c->N; P.Rt = c->d_Rt;
     P.rows = c->rows; P.NP = c->NP; P.npairs = c->npairs; P.nslices = c->nslices;
     P.A = c->d_A; P.nA = c->nA; P.test_gen = c->d_test_gen; P.win_lo = c->d_win_lo; P.win_hi = c->d_win_hi;
-    P.center = c->d_center; P.center_hi = c->d_center_hi; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi;
+    P.center = c->d_center; P.center_hi = c->d_center_hi; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi; P.rmax = c->rmax;
     P.part_T = c->d_part_T; P.part_lin = c->d_part_lin; P.part_ns = c->d_part_ns;
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
     if (const char *pad = getenv("BMX_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments

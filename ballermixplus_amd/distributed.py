@@ -37,6 +37,7 @@ class World:
     def __init__(self, rank=0, size=1, local_rank=0, backend=None):
         self.rank, self.size, self.local_rank, self.backend = rank, size, local_rank, backend
         self._own_pg = False
+        self.force = False
 
     @classmethod
     def from_env(cls, backend=None):
@@ -44,7 +45,10 @@ class World:
         rank = int(os.environ.get('RANK', '0'))
         local = int(os.environ.get('LOCAL_RANK', '0'))
         w = cls(rank, size, local, backend)
-        if size > 1:
+        # BMX_FORCE_DIST=1: initialise the process group even for a single rank, so that the RCCL
+        # gather path can be exercised on a 1-GPU box (tests)
+        w.force = os.environ.get('BMX_FORCE_DIST') == '1'
+        if size > 1 or w.force:
             import torch
             import torch.distributed as dist
             if backend is None:
@@ -54,12 +58,17 @@ class World:
                 torch.cuda.set_device(local)
             if not dist.is_initialized():
                 os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                os.environ.setdefault('MASTER_PORT', '29533')
                 dist.init_process_group(backend=backend, rank=rank, world_size=size)
                 w._own_pg = True
         return w
 
+    @property
+    def distributed(self):
+        return self.size > 1 or self.force
+
     def finish(self):
-        if self.size > 1:
+        if self.distributed:
             import torch.distributed as dist
             dist.barrier()
             if self._own_pg:

@@ -103,7 +103,40 @@ class _Gather:
         return self.tab[self.row[sub]]
 
 
+class _QuietStdout:
+    """RCCL prints a version banner through C stdio on stdout (flushed at exit, i.e. after
+    anything Python printed).  The contract is ONE JSON line on stdout, so fd 1 points at stderr
+    while the job runs and is restored, after a C-level flush, just before the line is printed."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def restore(self):
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.saved, 1)
+
+    def __exit__(self, *a):
+        return False
+
+
 def main():
+    with _QuietStdout() as quiet:
+        line = _run()
+        quiet.restore()
+    if line is not None:
+        print(line)
+        sys.stdout.flush()
+
+
+def _run():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
@@ -146,7 +179,7 @@ def main():
     bytes_per_step = float(wmax.sum()) * 10.0 + 24.0 * N      # W_max*10 B + 24 B per window
 
     def gather():
-        if world.size > 1:
+        if world.distributed:
             pc, pl, pn = ctx.result_ptrs()
             d = torch.device('cuda', dev)
             clr = torch.as_tensor(distributed._DevArray(pc, N, '<f8'), device=d)
@@ -161,7 +194,7 @@ def main():
         return None
 
     def barrier():
-        if world.size > 1:
+        if world.distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -179,7 +212,7 @@ def main():
         gather()
     barrier()
     dt = time.perf_counter() - t0
-    if world.size > 1:
+    if world.distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device('cuda', dev))
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -223,9 +256,12 @@ def main():
         }
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(gen, k, nn, spect, props, grid, args.cpu_windows, 256)
-        print(json.dumps(res))
+        line = json.dumps(res)
+    else:
+        line = None
     ctx.close()
     world.finish()
+    return line
 
 
 if __name__ == '__main__':

@@ -250,3 +250,24 @@ def test_abi_error_paths():
     with pytest.raises(_lib.BmxError):
         engine.Context(999)
     ctx.close()
+
+
+def test_rccl_gather_path_single_rank(tmp_path):
+    """The multi-GPU code path (NCCL process group, zero-copy view of the library's device
+    buffers, all_gather_into_tensor, reassembly) exercised with one rank on this box: the CLI
+    under BMX_FORCE_DIST=1 must write the same file as the plain single-process run."""
+    import subprocess
+    import sys
+    from util import REPO
+    argv, gold = cases.ALL_CASES['ex1_B2_w50_s25']
+    outs = []
+    for force in ('0', '1'):
+        out = tmp_path / ('o%s.txt' % force)
+        env = dict(os.environ, BMX_FORCE_DIST=force, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+        subprocess.run([sys.executable, os.path.join(REPO, 'BalLeRMixPlus_amd.py')] + argv + ['-o', str(out)],
+                       check=True, env=env, stdout=subprocess.DEVNULL, timeout=600)
+        outs.append(out.read_text())
+    assert outs[0] == outs[1]
+    worst, ties = cases.compare_rows(outs[1].splitlines(True)[1:], gold)
+    assert worst < 1e-6 and ties == 0
