@@ -378,10 +378,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanPara
         int L_int = min(c0, hi_min + 1), R_int = max(cU, lo_max);
         if (hi_min < lo_max) { L_int = c0; R_int = c0; hi_min = -1; lo_max = N; }   // no bulk zone
 
+        // running best per test site: key = (clamped exponent + 2^17) << 13 | iA  (iA = 8191: none yet)
         double acc[J], bestM[J];
-        int E[J], bestE[J], bestLin[J];
+        int E[J], bestK[J];
 #pragma unroll
-        for (int j = 0; j < J; ++j) { bestE[j] = 0; bestM[j] = 1.0; bestLin[j] = 0x7fffffff; }
+        for (int j = 0; j < J; ++j) { bestM[j] = 1.0; bestK[j] = (131072 << 13) | 8191; }
 
         for (int iA = 0; iA < P.nA; ++iA) {
             const double A = P.A[iA];
@@ -483,16 +484,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanPara
                         if (MODE == 1) {
                             scr[lane] = ScratchEnt{Ev, rowoff, 0};
                             __builtin_amdgcn_wave_barrier();
-                            for (int l0 = 0; l0 < cnt; l0 += 8) {
-                                spend(span8);
-                                double v[8];
+                            constexpr int BS = J >= 16 ? 4 : 8;        // sites per unrolled block
+                            for (int l0 = 0; l0 < cnt; l0 += BS) {
+                                spend(span8 * BS / 8);
+                                double v[BS];
 #pragma unroll
-                                for (int u = 0; u < 8; ++u) {       // lanes >= cnt carry Ev = 0: factor 1
+                                for (int u = 0; u < BS; ++u) {      // lanes >= cnt carry Ev = 0: factor 1
                                     const ScratchEnt en = scr[l0 + u];     // uniform address: LDS broadcast
                                     v[u] = en.e * loadR(en.ro);
                                 }
 #pragma unroll
-                                for (int u = 0; u < 8; u += 2) {
+                                for (int u = 0; u < BS; u += 2) {
                                     const double sv = v[u] + v[u + 1], qv = v[u] * v[u + 1];
 #pragma unroll
                                     for (int j = 0; j < J; ++j) acc[j] *= fma(F[j], fma(F[j], qv, sv), 1.0);
@@ -531,18 +533,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanPara
             renorm_all();
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                const bool better = (E[j] > bestE[j]) || (E[j] == bestE[j] && acc[j] > bestM[j]);
+                const int ec = min(max(E[j], -131071), 131071) + 131072;
+                const int eb = bestK[j] >> 13;
+                const bool better = (ec > eb) || (ec == eb && acc[j] > bestM[j]);
                 if (better && p < P.npairs) {            // strict '>' (v1:501); iA ascending
-                    bestE[j] = E[j];
                     bestM[j] = acc[j];
-                    bestLin[j] = iA * P.npairs + p;
+                    bestK[j] = (ec << 13) | iA;
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            double bT = bestLin[j] == 0x7fffffff ? 0.0 : 2.0 * ((double)bestE[j] * LN2 + log(bestM[j]));
-            int bL = bestLin[j];
+            const int biA = bestK[j] & 8191;
+            double bT = biA == 8191 ? 0.0 : 2.0 * ((double)((bestK[j] >> 13) - 131072) * LN2 + log(bestM[j]));
+            int bL = biA == 8191 ? 0x7fffffff : biA * P.npairs + p;
             for (int off = 32; off > 0; off >>= 1) {
                 const double oT = __shfl_xor(bT, off);
                 const int oL = __shfl_xor(bL, off);
@@ -903,13 +907,13 @@ int bmx_ctx_scan(bmx_ctx *c) {
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
     if (const char *pad = getenv("BMX_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
     const bool fits = lds + (size_t)SCAN_THREADS * sizeof(ScratchEnt) <= (size_t)LDS_LIMIT_BYTES;
-    const bool can_group = c->tests_sorted && c->span_hi <= 62 && c->N < 0x7fffffffLL;
+    const bool can_group = c->tests_sorted && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
     int J = 0;
-    // variants: 0 -> J=8 pair/LDS-broadcast (default); 3 -> J=16, 4 -> J=4 (same mode);
+    // variants: 0 -> J=16 pair/LDS-broadcast (default); 3 -> J=8, 4 -> J=4 (same mode);
     //           5/6/7 -> J=16/8/4 with the readlane single-site inner loop; 1, 2 -> per-site kernel
     if (can_group) {
         const int v = c->variant;
-        J = (v == 3 || v == 5) ? 16 : (v == 0 || v == 6) ? 8 : (v == 4 || v == 7) ? 4 : 0;
+        J = (v == 0 || v == 5) ? 16 : (v == 3 || v == 6) ? 8 : (v == 4 || v == 7) ? 4 : 0;
     }
     P.sites_per_block = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : 4);
     if (J == 16 && P.sites_per_block < 64) P.sites_per_block = 64;
