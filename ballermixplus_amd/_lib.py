@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbmxscan.so')
+LIB_PATH = os.path.join(_HERE, os.environ.get('BMX_LIB_NAME', 'libbmxscan.so'))   # BMX_LIB_NAME: A/B builds
 
 
 class BmxError(RuntimeError):

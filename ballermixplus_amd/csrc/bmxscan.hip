@@ -58,7 +58,8 @@ bool trace_on() {
     } while (0)
 
 constexpr int WAVE = 64;
-constexpr int SCAN_THREADS = 256;             // 4 waves per workgroup
+constexpr int SCAN_THREADS = 256;             // 4 waves per workgroup (default)
+constexpr int SCAN_THREADS_MAX = 512;         // 8 waves when one R slice fills most of a CU's LDS
 constexpr int LDS_LIMIT_BYTES = 160 * 1024;   // gfx950: 160 KiB per CU
 constexpr double LN2 = 0.693147180559945309417232121458;
 
@@ -331,7 +332,7 @@ struct alignas(16) ScratchEnt {
 };
 
 template <int J, bool USE_LDS, int MODE>
-__global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanParams P) {
+__global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(ScanParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then scratch
     constexpr int SP = WAVE / J;                                    // sites per generic pass
     const int lane = threadIdx.x & (WAVE - 1);
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanPara
 
     if (USE_LDS) {
         const int total = P.rows * WAVE;
-        for (int idx = threadIdx.x; idx < total; idx += SCAN_THREADS)
+        for (int idx = threadIdx.x; idx < total; idx += blockDim.x)
             lds_R[idx] = P.Rt[(size_t)(idx >> 6) * P.NP + slice * WAVE + (idx & 63)];
         __syncthreads();
     }
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_grouped_kernel(ScanPara
     const int64_t ngroups = (P.M + J - 1) / J;
     const int64_t gpb = P.sites_per_block / J;
     const int64_t g_end = min((chunk + 1) * gpb, ngroups);
-    for (int64_t grp = chunk * gpb + wave; grp < g_end; grp += SCAN_THREADS / WAVE) {
+    for (int64_t grp = chunk * gpb + wave; grp < g_end; grp += blockDim.x / WAVE) {
         const int64_t tb = grp * J;
         const int nvalid = (int)min((int64_t)J, P.M - tb);
         const int jj = min(jl, nvalid - 1);
@@ -661,6 +662,7 @@ struct bmx_ctx {
     double *d_test_gen = nullptr;
     int64_t *d_win_lo = nullptr, *d_win_hi = nullptr, *d_center = nullptr, *d_center_hi = nullptr;
     bool tests_sorted = false;
+    bool tests_dense = false;   // neighbouring test sites are a few sites apart (median index gap <= 32)
     double *d_part_T = nullptr;
     int32_t *d_part_lin = nullptr, *d_part_ns = nullptr;
     double *d_clr = nullptr;
@@ -889,6 +891,18 @@ int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64
                        c->d_genpos, c->N, c->d_test_gen, M, c->d_center, c->d_center_hi);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
+    {   // test-site density from a sample of the located positions (decides grouped vs per-site kernel)
+        const int64_t ns = std::min<int64_t>(M, 65536);
+        std::vector<int64_t> hc((size_t)ns);
+        HIP_TRY(hipMemcpy(hc.data(), c->d_center, (size_t)ns * sizeof(int64_t), hipMemcpyDeviceToHost));
+        std::vector<int64_t> gaps;
+        for (int64_t t = 1; t < ns; t++) gaps.push_back(hc[(size_t)t] - hc[(size_t)t - 1]);
+        c->tests_dense = false;
+        if (!gaps.empty()) {
+            std::nth_element(gaps.begin(), gaps.begin() + gaps.size() / 2, gaps.end());
+            c->tests_dense = gaps[gaps.size() / 2] <= 32;
+        }
+    }
     c->M = M;
     c->has_tests = true;
     return BMX_OK;
@@ -906,8 +920,10 @@ int bmx_ctx_scan(bmx_ctx *c) {
     P.part_T = c->d_part_T; P.part_lin = c->d_part_lin; P.part_ns = c->d_part_ns;
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
     if (const char *pad = getenv("BMX_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
-    const bool fits = lds + (size_t)SCAN_THREADS * sizeof(ScratchEnt) <= (size_t)LDS_LIMIT_BYTES;
-    const bool can_group = c->tests_sorted && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
+    const bool fits = lds + (size_t)SCAN_THREADS_MAX * sizeof(ScratchEnt) <= (size_t)LDS_LIMIT_BYTES;
+    // grouping pays when neighbouring test sites share most of their windows; a strided scan
+    // (-s far larger than 1) is better served one test site per wave
+    const bool can_group = c->tests_sorted && c->tests_dense && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
     int J = 0;
     // variants: 0 -> J=16 pair/LDS-broadcast (default); 3 -> J=8, 4 -> J=4 (same mode);
     //           5/6/7 -> J=16/8/4 with the readlane single-site inner loop; 1, 2 -> per-site kernel
@@ -934,11 +950,22 @@ int bmx_ctx_scan(bmx_ctx *c) {
     else fn = PICK(clr_scan_kernel);
 #undef GPICK
 #undef PICK
-    size_t lds_bytes = (use_lds ? lds : 0) + (J ? (size_t)SCAN_THREADS * sizeof(ScratchEnt) : 0);
+    // One wave per SIMD issues FP64 at half rate (measured), so a workgroup whose LDS footprint
+    // allows only one resident workgroup per CU gets 8 waves instead of 4.
+    int threads = SCAN_THREADS;
+    size_t lds_bytes = (use_lds ? lds : 0) + (J ? (size_t)threads * sizeof(ScratchEnt) : 0);
+    if (J && 2 * lds_bytes > (size_t)LDS_LIMIT_BYTES) {
+        threads = SCAN_THREADS_MAX;
+        lds_bytes = (use_lds ? lds : 0) + (size_t)threads * sizeof(ScratchEnt);
+        P.sites_per_block *= 2;
+        chunks = (c->M + P.sites_per_block - 1) / P.sites_per_block;
+        blocks = chunks * c->nslices;
+    }
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return fail(BMX_E_LIMIT, "LDS budget exceeded");
     if (lds_bytes) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     void *kargs[] = {&P};
-    HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(SCAN_THREADS), kargs, lds_bytes, c->stream));
+    TRACE("scan: launch %lld blocks x %d threads, %zu B LDS", (long long)blocks, threads, lds_bytes);
+    HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(threads), kargs, lds_bytes, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     FinalParams F;
     F.part_T = c->d_part_T; F.part_lin = c->d_part_lin; F.part_ns = c->d_part_ns;
@@ -946,8 +973,8 @@ int bmx_ctx_scan(bmx_ctx *c) {
     F.genpos = c->d_genpos; F.A = c->d_A; F.test_gen = c->d_test_gen; F.win_lo = c->d_win_lo; F.win_hi = c->d_win_hi;
     F.center = c->d_center; F.center_hi = c->d_center_hi; F.zcut = c->zcut;
     F.clr = c->d_clr; F.lin = c->d_lin; F.nsites = c->d_nsites;
-    int threads = 256;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((c->M + threads - 1) / threads)), dim3(threads), 0, c->stream, F);
+    const int fthreads = 256;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((c->M + fthreads - 1) / fthreads)), dim3(fthreads), 0, c->stream, F);
     HIP_TRY(hipGetLastError());
     c->timed = true;
     return BMX_OK;

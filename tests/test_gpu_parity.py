@@ -271,3 +271,44 @@ def test_rccl_gather_path_single_rank(tmp_path):
     assert outs[0] == outs[1]
     worst, ties = cases.compare_rows(outs[1].splitlines(True)[1:], gold)
     assert worst < 1e-6 and ties == 0
+
+
+@pytest.mark.parametrize('sizes,label', [((40, 50, 60), 'lds'), ((150, 160, 170), 'global-R'), ((200,), 'lds-8-wave')])
+def test_multiple_sample_sizes_and_large_tables(sizes, label):
+    """Ragged input: several sample sizes in one file (missing data), LUT rows = sum(n+1).
+    (150,160,170) gives 483 rows = 247 KB per slice > LDS, so R is read from global memory;
+    (200,) fills most of a CU's LDS and runs 8 waves per workgroup.  Dense test sites (grouped
+    kernel) and strided test sites (per-site kernel) are both compared with the C oracle."""
+    eng = _engine()
+    L = c_oracle()
+    from ballermixplus_amd.hostmodel import Grids
+    rng = np.random.default_rng(11)
+    N = 6000
+    gen = np.cumsum(rng.geometric(1 / 60.0, N)) / 1e6
+    nn = rng.choice(np.array(sizes), N)
+    k = np.where(rng.random(N) < 0.6, nn, (rng.random(N) * (nn - 1)).astype(int) + 1)
+    cnt = {}
+    for a, b in zip(k.tolist(), nn.tolist()):
+        cnt[(a, b)] = cnt.get((a, b), 0) + 1
+    spect = {key: v / N for key, v in cnt.items()}
+    props = {int(n): sum(v for (a, b), v in spect.items() if b == n) for n in sizes}
+    grid = Grids(None, None, True, False, None, '150,400,1000,2500,6000,20000')
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays('B2', int(k.min()), sizes, spect, props, xs, ab)
+    rows = model.rows_of(k, nn)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, rows)
+    _, R = ctx.fetch_lut()
+    Rfin = np.where(np.isfinite(R), R, 0.0)
+    for idx in (np.arange(1000, 1700), np.arange(0, N, 37)):
+        lo = np.zeros(len(idx), np.int64)
+        hi = np.full(len(idx), N - 1, np.int64)
+        ctx.set_tests(gen[idx], lo, hi)
+        ctx.scan()
+        got = ctx.fetch()
+        ref = c_scan(L, Rfin, As, gen, rows, gen[idx], lo, hi)
+        for f in (1, 2, 3, 4):
+            assert np.array_equal(got[f], ref[f]), (label, f)
+        assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-12)
+    ctx.close()
