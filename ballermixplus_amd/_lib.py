@@ -55,6 +55,8 @@ PROTOTYPES = {
     'bmx_ctx_result_ptrs': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     'bmx_ctx_fetch_lut': (C.c_int, [_vp, _dp, _dp]),
     'bmx_ctx_set_variant': (C.c_int, [_vp, C.c_int]),
+    'bmx_input_count': (C.c_int, [C.c_char_p, _lp]),
+    'bmx_input_parse': (C.c_int, [C.c_char_p, C.c_int64, C.c_int, _lp, _dp, _lp, _lp]),
 }
 
 _lib = None
@@ -103,3 +105,18 @@ def i32(a):
 
 def i64(a):
     return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def read_input(path, pos_col):
+    """(phys i64[N], coord f64[N], k i64[N], n i64[N]) through the native reader."""
+    L = lib()
+    n = C.c_int64()
+    check(L.bmx_input_count(path.encode(), C.byref(n)))
+    N = n.value
+    phys = np.empty(N, dtype=np.int64)
+    coord = np.empty(N, dtype=np.float64)
+    k = np.empty(N, dtype=np.int64)
+    nn = np.empty(N, dtype=np.int64)
+    if N:
+        check(L.bmx_input_parse(path.encode(), N, int(pos_col), as_lp(phys), as_dp(coord), as_lp(k), as_lp(nn)))
+    return phys, coord, k, nn

@@ -726,6 +726,7 @@ void bmx_version(int *major, int *minor) {
 }
 
 const char *bmx_last_error(void) { return g_err.c_str(); }
+void bmx_set_error_(const char *msg) { g_err = msg ? msg : ""; }   // for the library's other translation units
 
 int bmx_device_count(void) {
     int n = 0;

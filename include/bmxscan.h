@@ -131,6 +131,16 @@ int bmx_ctx_fetch_lut(bmx_ctx *c, double *psel_out, double *R_out);
 /* Choose the scan kernel variant (0 = default). For A/B measurements only. */
 int bmx_ctx_set_variant(bmx_ctx *c, int variant);
 
+/* ---- input ingest (host only) ------------------------------ */
+/* Native reader of the 4-column input that InputData.readCounts / readPolyCalls parse line by
+ * line in Python (BalLeRMix+_v1.py:80-131): header skipped, tab-separated physPos, genPos, k, n.
+ * bmx_input_count returns the number of data lines; bmx_input_parse fills caller-allocated arrays
+ * of that length: phys = int(float(col0)), coord = float(col[pos_col]) (pos_col 0: physical,
+ * 1: genetic), k = int(col2), n = int(col3).  Bit-identical to the Python parse (strtod). */
+int bmx_input_count(const char *path, int64_t *n_out);
+int bmx_input_parse(const char *path, int64_t N, int pos_col, int64_t *phys, double *coord,
+                    int64_t *k, int64_t *n);
+
 #ifdef __cplusplus
 }
 #endif

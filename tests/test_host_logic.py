@@ -121,3 +121,39 @@ def test_window_bounds_of_each_mode():
         lo, hi = ts.lo[j], ts.hi[j]
         assert p.position[lo] >= p.position[i] - 2500 and (lo == 0 or p.position[lo - 1] < p.position[i] - 2500)
         assert hi == len(p.position) - 1 or p.position[hi] >= min(p.position[i] + 2500, p.position[-1])
+
+
+@pytest.mark.parametrize('fname,kw', [
+    ('Example1_fullSweep_200kya_DAF.txt', {}),
+    ('Example1_fullSweep_200kya_DAF.txt', dict(nofreq=True)),
+    ('Example2_balancing_10MYA_MAF_nosub.txt', dict(phys=True, Rrate=1.25e-6)),
+    ('Example2_balancing_10MYA_DAF.txt', dict(MAF=True)),
+])
+def test_native_reader_equals_reference_text_loop(fname, kw):
+    """libbmxscan's mmap/strtod reader vs the reference's per-line parse."""
+    path = os.path.join(REFT, fname)
+    fast = InputData(path, **kw)
+    slow = InputData.__new__(InputData)
+    slow.numSites = 0
+    pos_type = 1 - int(kw.get('phys', False))
+    p, g, c, t = slow._read(path, pos_type, kw.get('Rrate', 1e-6), kw.get('nofreq', False))
+    nat = fast._read_native(path, pos_type, kw.get('Rrate', 1e-6), kw.get('nofreq', False))
+    assert nat is not None, 'native reader unavailable'
+    assert np.array_equal(nat[0], np.array(p)) and np.array_equal(nat[1], np.array(g))
+    assert np.array_equal(nat[2], np.array(c).astype(np.int64)) and np.array_equal(nat[3], np.array(t))
+    assert nat[1].dtype == np.float64 and slow.numSites == len(nat[0])
+
+
+def test_native_reader_edge_cases(tmp_path):
+    from ballermixplus_amd import _lib
+    f = tmp_path / 'a.txt'
+    f.write_text('physPos\tgenPos\tx\tn\n12.0\t1.2e-07\t50\t50\r\n165\t1.65e-06\t3\t50')   # CRLF + no final newline
+    ph, co, k, n = _lib.read_input(str(f), 1)
+    assert ph.tolist() == [12, 165] and co.tolist() == [1.2e-07, 1.65e-06] and k.tolist() == [50, 3] and n.tolist() == [50, 50]
+    f.write_text('physPos\tgenPos\tx\tn\n')
+    assert len(_lib.read_input(str(f), 0)[0]) == 0
+    f.write_text('physPos\tgenPos\tx\tn\n12\t0.1\tfoo\t50\n')
+    with pytest.raises(_lib.BmxError):
+        _lib.read_input(str(f), 1)
+    with pytest.raises(_lib.BmxError):
+        _lib.read_input(str(tmp_path / 'missing.txt'), 1)
