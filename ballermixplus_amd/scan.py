@@ -38,6 +38,17 @@ class TestSites:
     def add_na(self, line):
         self.na_rows[len(self.order) + len(self.na_rows)] = line
 
+    def add_many(self, phys, gen_label, test_gen, lo, hi):
+        """Vectorised add() for modes whose test sites are a plain index stride."""
+        assert not self.na_rows
+        n0 = len(self.order)
+        self.order.extend(range(n0, n0 + len(phys)))
+        self.phys.extend(phys)
+        self.gen_label.extend(gen_label)
+        self.test_gen.extend(test_gen)
+        self.lo.extend(lo)
+        self.hi.extend(hi)
+
     def __len__(self):
         return len(self.order)
 
@@ -46,11 +57,9 @@ def sites_alpha(data, s):
     """_alpha, v1:598-610: every int(s)-th site, window = all sites."""
     ts = TestSites()
     N = data.numSites
-    step = int(s)
-    i = 0
-    while i < N:
-        ts.add(data.position[int(i)], data.genPos[int(i)], data.genPos[int(i)], 0, N - 1)
-        i += step
+    idx = np.arange(0, N, int(s))
+    g = data.genPos[idx].tolist()
+    ts.add_many(data.position[idx].tolist(), g, g, [0] * len(idx), [N - 1] * len(idx))
     return ts
 
 
@@ -141,13 +150,26 @@ def format_row(phys, gen_label, clr, ix, ia, iA, ns, sel):
 
 
 def write_rows(outfile, ts, results, sel):
+    """All rows of the output file.  Same text as format_row per row, built column-wise
+    (a million-row file is otherwise dominated by per-row Python formatting)."""
     clr, ix, ia, iA, ns = results
     total = len(ts) + len(ts.na_rows)
-    lines = [None] * total
-    for pos, line in ts.na_rows.items():
-        lines[pos] = line
-    for j, pos in enumerate(ts.order):
-        lines[pos] = format_row(ts.phys[j], ts.gen_label[j], clr[j], int(ix[j]), int(ia[j]), int(iA[j]), ns[j], sel)
+    xs = [f'{v}' for v in sel.grid_x]
+    abs_ = [f'{v}' for v in sel.grid_abeta]
+    As = [f'{v}' for v in sel.grid_A]
+    phys = [float(v) if isinstance(v, np.floating) else v for v in ts.phys]
+    gen = [float(v) if isinstance(v, np.floating) else v for v in ts.gen_label]
+    body = [f'{p}\t{g}\t{c}\t{xs[a]}\t{abs_[b]}\t{As[d]}\t{n}\n' if d >= 0 else f'{p}\t{g}\t0.0\t0.0\t0.0\t0.0\t0.0\n'
+            for p, g, c, a, b, d, n in zip(phys, gen, np.asarray(clr, dtype=np.float64).tolist(), np.asarray(ix).tolist(),
+                                           np.asarray(ia).tolist(), np.asarray(iA).tolist(), np.asarray(ns).tolist())]
+    if ts.na_rows:
+        lines = [None] * total
+        for pos, line in ts.na_rows.items():
+            lines[pos] = line
+        for j, pos in enumerate(ts.order):
+            lines[pos] = body[j]
+    else:
+        lines = body
     with open(outfile, 'w') as scores:
         scores.write(HEADER)
         scores.writelines(lines)

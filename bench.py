@@ -25,8 +25,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64: 256 CU x 4 SIMD x 16 lane
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6300 achievable)
 # executed FP64 flop per evaluation (one site x one grid pair x one test site) in the default kernel:
 # bulk sites go two at a time, (1+F v1)(1+F v2) = 1 + F*(s + F*q): 2 FMA + 1 MUL = 5 flop per pair and
-# test site, plus v1, v2, s, q (4 flop) shared by the J = 8 test sites of a group: 2.5 + 4/16 = 2.75
-FLOP_PER_EVAL = 2.75
+# test site, plus v1, v2, s, q (4 flop) shared by the J = 16 test sites of a group: 2.5 + 4/32 = 2.625
+FLOP_PER_EVAL = 2.625
 SURVEY_FLOP_PER_EVAL = 32        # SURVEY.md 8(d) convention for the reference's FMA + log1p form
 
 
