@@ -239,7 +239,7 @@ def _run():
                        'parallelism': 'test-site sharding, dp%d, RCCL all_gather of 16-B records per step' % world.size,
                        'checksum_clr_rank0': checksum},
             'roofline': {
-                'bound': 'valu_fp64', 'kernel': 'clr_scan_kernel',
+                'bound': 'valu_fp64', 'kernel': 'clr_scan_grouped_kernel<16,true,1>',
                 'achieved': evals_s * FLOP_PER_EVAL / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': evals_s * FLOP_PER_EVAL / 1e12 / FP64_VALU_PEAK_TFLOPS, 'traffic': None,
                 'kernel_ms': k_ms, 'evals_per_launch': evals_per_step, 'evals_per_s': evals_s,
@@ -249,7 +249,7 @@ def _run():
                         'per test site per pair of sites; peak = vector FP64 (no contraction exists in this path, '
                         'so not MFMA); survey_convention = SURVEY 8(d) "1 evaluation = 32 flop"'},
             'roofline_hbm': {
-                'bound': 'hbm', 'kernel': 'clr_scan_kernel',
+                'bound': 'hbm', 'kernel': 'clr_scan_grouped_kernel<16,true,1>',
                 'achieved': bytes_per_step / (k_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': bytes_per_step / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                 'algorithmic_bytes_per_launch': bytes_per_step},
