@@ -312,3 +312,82 @@ def test_multiple_sample_sizes_and_large_tables(sizes, label):
             assert np.array_equal(got[f], ref[f]), (label, f)
         assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-12)
     ctx.close()
+
+
+@pytest.mark.parametrize('seed', list(range(12)))
+def test_randomised_scenarios_against_oracle(seed):
+    """Seeded random inputs through both kernels (grouped and per-site) vs the C oracle: random
+    densities (windows from a few sites to thousands), exact position ties, several sample sizes,
+    random statistic, random step, random fixed-index windows (some empty, some not containing the
+    test position), off-grid and duplicated test positions, tiny and huge A values."""
+    eng = _engine()
+    L = c_oracle()
+    from ballermixplus_amd.hostmodel import Grids
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.integers(300, 4000))
+    scale = 10.0 ** rng.uniform(-7.5, -4.0)
+    gen = np.cumsum(rng.geometric(0.2, N)).astype(np.float64) * scale
+    if seed % 3 == 0:
+        gen = np.round(gen / (scale * 3)) * (scale * 3)          # exact ties
+    gen = np.sort(gen)
+    sizes = tuple(sorted(set(int(v) for v in rng.choice([12, 20, 33, 50, 64], int(rng.integers(1, 4))))))
+    nn = rng.choice(np.array(sizes), N)
+    stat = ['B2', 'B2maf', 'B0', 'B0maf', 'B1'][seed % 5]
+    if stat == 'B1':
+        k = (rng.random(N) < 0.3).astype(np.int64)
+    elif stat.endswith('maf'):
+        lo_k = 1 if stat == 'B0maf' else 0
+        k = np.array([rng.integers(lo_k, n // 2 + 1) for n in nn])
+    else:
+        hi_k = nn - 1 if stat == 'B0' else nn
+        k = np.array([rng.integers(1, h + 1) for h in hi_k])
+    cnt = {}
+    for a, b in zip(k.tolist(), nn.tolist()):
+        cnt[(a, b)] = cnt.get((a, b), 0) + 1
+    spect = {key: v / N for key, v in cnt.items()}
+    props = {int(n): sum(v for (a, b), v in spect.items() if b == n) for n in sizes}
+    listA = ','.join(repr(float(v)) for v in 10.0 ** rng.uniform(0.5, 9.0, int(rng.integers(2, 9))))
+    grid = Grids(None, None, bool(seed % 2), False, None, listA)
+    xs, ab, As = grid.scan_order()
+    minc = int(k[k > 0].min()) if stat.endswith('maf') else (1 if stat == 'B1' else int(k.min()))
+    model = eng.ModelArrays(stat, minc, sizes, spect, props, xs, ab)
+    rows = model.rows_of(k, nn)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, rows)
+    _, R = ctx.fetch_lut()
+    Rfin = np.where(np.isfinite(R), R, 0.0)
+    step = int(rng.integers(1, 4))
+    idx = np.arange(0, N, step)
+    tg = gen[idx].copy()
+    off = rng.random(len(tg)) < 0.1
+    tg[off] += scale * 0.37                                          # off-grid test positions
+    tg = np.sort(np.concatenate([tg, tg[:5]]))                       # duplicated test positions
+    M = len(tg)
+    mode = seed % 4
+    if mode == 0:
+        lo, hi = np.zeros(M, np.int64), np.full(M, N - 1, np.int64)
+    else:
+        c = np.searchsorted(gen, tg)
+        r = int(rng.integers(1, 200))
+        lo = np.maximum(c - r, 0).astype(np.int64)
+        hi = np.minimum(c + r + 1, N - 1).astype(np.int64)
+        if mode == 2:
+            lo = np.minimum(lo + rng.integers(0, 2 * r, M), N - 1)   # ragged, sometimes empty, sometimes past the test site
+        if mode == 3:
+            hi = np.maximum(hi - rng.integers(0, 2 * r, M), 0)
+    ref = c_scan(L, Rfin, As, gen, rows, tg, lo, hi)
+    for variant in (0, 2, 3):
+        ctx.set_variant(variant)
+        ctx.set_tests(tg, lo, hi)
+        ctx.scan()
+        got = ctx.fetch()
+        # exact integer fields, except grid points tied within rounding noise (saturated tables)
+        same = (got[1] == ref[1]) & (got[2] == ref[2]) & (got[3] == ref[3])
+        assert np.array_equal(got[4][same], ref[4][same]), (seed, variant)
+        assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-12), (seed, variant)
+        assert same.mean() > 0.97, (seed, variant, same.mean())
+        for t in np.nonzero(~same)[0][:20]:          # a different argmax must be a tie to 1e-9
+            assert got[3][t] >= 0 and ref[3][t] >= 0
+            assert abs(got[0][t] - ref[0][t]) <= 1e-9 * abs(ref[0][t]) + 1e-12
+    ctx.close()
