@@ -75,6 +75,7 @@ struct LutParams {
     double *psel;  // [nx][nab][rows]
     double *R;     // [nx][nab][rows]
     double *Rt;    // [rows][NP]   kernel layout: pair index fastest, zero padded
+    bmx::LogPatch patch;   // host-libm conformance exceptions for lgam's log (bmx_math.h)
 };
 
 // One thread per (grid pair, LUT row).  The thread needs the beta-binomial pmf at the site's own
@@ -118,7 +119,7 @@ __global__ void bb_lut_kernel(LutParams P) {
             const double b = side ? b2 : b1;
             double pr = 0.;
             for (int f = 0; f < nfold; ++f) {
-                const double q = bmx::betabinom_pmf(f ? n - c : c, n, a, b);
+                const double q = bmx::betabinom_pmf(f ? n - c : c, n, a, b, P.patch);
                 pr = f ? pr + q : q;
             }
             if (site && maf && (n % 2 == 0) && c == n / 2) pr = pr / 2;      // v1:391-392
@@ -650,6 +651,9 @@ struct bmx_ctx {
     int32_t *d_sizes = nullptr, *d_row_off = nullptr;
     double *d_g = nullptr, *d_prop = nullptr, *d_x = nullptr, *d_abeta = nullptr, *d_A = nullptr;
     double *d_psel = nullptr, *d_R = nullptr, *d_Rt = nullptr;
+    uint64_t *d_patch_x = nullptr;
+    double *d_patch_y = nullptr;
+    int n_patch = 0;
     std::vector<double> h_g;
     // sites
     bool has_sites = false;
@@ -675,6 +679,7 @@ namespace {
 void free_model(bmx_ctx *c) {
     dfree(c->d_sizes); dfree(c->d_row_off); dfree(c->d_g); dfree(c->d_prop); dfree(c->d_x);
     dfree(c->d_abeta); dfree(c->d_A); dfree(c->d_psel); dfree(c->d_R); dfree(c->d_Rt);
+    dfree(c->d_patch_x); dfree(c->d_patch_y);
     c->has_model = false;
 }
 void free_sites(bmx_ctx *c) {
@@ -805,7 +810,47 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     HIP_TRY(hipMalloc((void **)&c->d_R, tab * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_Rt, (size_t)c->rows * c->NP * sizeof(double)));
     HIP_TRY(hipMemsetAsync(c->d_Rt, 0, (size_t)c->rows * c->NP * sizeof(double), c->stream));
+    // host-libm conformance patch (bmx_math.h): every argument that K1 takes a log of inside lgam's
+    // Stirling branch, evaluated with this host's libm and with the device's correctly rounded log
+    std::vector<uint64_t> px;
+    std::vector<double> py;
+    {
+        auto consider = [&](double v) {
+            if (!(v >= 13.0) || !(v < 1e300)) return;     // lgam's log(x) branch starts at 13
+            const double hl = log(v);
+            if (hl != bmx::crlog(v)) {
+                uint64_t b;
+                memcpy(&b, &v, sizeof(b));
+                if (std::find(px.begin(), px.end(), b) == px.end() && px.size() < 4096) { px.push_back(b); py.push_back(hl); }
+            }
+        };
+        int nmax = 0;
+        for (int j = 0; j < m->n_sizes; j++) nmax = std::max(nmax, m->sizes[j]);
+        for (int ix = 0; ix < m->nx; ix++)
+            for (int ia = 0; ia < m->nab; ia++) {
+                const double a = m->abeta[ia];
+                for (int side = 0; side < 2; side++) {
+                    const double xx = side ? 1. - m->x[ix] : m->x[ix];
+                    const double b = a / xx - a;
+                    consider(a); consider(b); consider(a + b);
+                    for (int j = 0; j < m->n_sizes; j++) {
+                        const int n = m->sizes[j];
+                        for (int k = 0; k <= n; k++) {
+                            const double p1 = k + a, q1 = n - k + b;
+                            consider(p1); consider(q1); consider(p1 + q1);
+                        }
+                    }
+                }
+            }
+    }
+    c->n_patch = (int)px.size();
+    TRACE("set_model: %d libm log exceptions", c->n_patch);
+    if (c->n_patch) {
+        if ((rc = upload(c->d_patch_x, (const uint64_t *)px.data(), px.size(), c->stream))) return rc;
+        if ((rc = upload(c->d_patch_y, (const double *)py.data(), py.size(), c->stream))) return rc;
+    }
     LutParams P;
+    P.patch = bmx::LogPatch{c->d_patch_x, c->d_patch_y, c->n_patch};
     P.stat = c->stat; P.min_count = c->min_count; P.n_sizes = c->n_sizes; P.rows = c->rows;
     P.nx = c->nx; P.nab = c->nab; P.NP = c->NP;
     P.sizes = c->d_sizes; P.row_off = c->d_row_off; P.g = c->d_g; P.prop = c->d_prop;

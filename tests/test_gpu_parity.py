@@ -40,9 +40,10 @@ def test_device_selection_table_matches_reference(path):
     rel = np.abs(got - ref) / np.abs(ref)
     # The large-argument lgam noise (alpha_beta >= 1e4) must be REPRODUCED, not merely
     # approximated: a 1-ulp-accurate log would already be off by 1e-5 at alpha_beta = 1e9.
-    # The device log is correctly rounded; glibc's (which scipy calls) is not on ~0.015 % of
-    # the arguments, and one such argument (x ~ 1e4, n = 200 table) moves one entry by 1.5e-11.
-    assert np.nanmax(rel) < 1e-9, float(np.nanmax(rel))
+    # The device log is correctly rounded; glibc's (which scipy calls) is not on ~0.015 % of the
+    # arguments; the host ships those exceptions (LogPatch), so nothing beyond exp/log-of-small
+    # ulp differences (amplified where normBase -> 0, e.g. B_0 at tiny alpha_beta) remains.
+    assert np.nanmax(rel) < 1e-12, float(np.nanmax(rel))
     assert np.allclose(R[:, :, rows], got - 1.0, rtol=0, atol=1e-15 * np.abs(got).max() + 1e-300)
     ctx.close()
 
