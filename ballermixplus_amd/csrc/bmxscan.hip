@@ -617,6 +617,49 @@ __global__ void finalize_kernel(FinalParams F) {
     F.nsites[t] = none ? 0 : bN;
 }
 
+// ----------------------------------------------------------------------------- surface
+// Full likelihood surface T[iA][pair] of ONE test site (the reference keeps only the maximum and
+// notes the surfaces as a wish, v1:449-450).  Deliberately a different arithmetic from the scan
+// kernels -- a plain sum of log1p(alpha*R) per (A, pair) -- so that it doubles as an on-device
+// cross-check of the product form.  One workgroup per (A, 64-pair slice); lanes = pairs.
+struct SurfParams {
+    const double *genpos; const uint16_t *row; int64_t N;
+    const double *Rt; int NP, npairs, nslices;
+    const double *A; int nA;
+    double tg; int64_t lo, hi;
+    double zcut;
+    double *T;        // [nA][npairs]
+    int32_t *ns;      // [nA]
+};
+
+__global__ void surface_kernel(SurfParams S) {
+    const int iA = blockIdx.x / S.nslices, slice = blockIdx.x % S.nslices;
+    const int lane = threadIdx.x;
+    const int p = slice * WAVE + lane;
+    const double A = S.A[iA];
+    double sum = 0.0;
+    int ns = 0;
+    for (int64_t base = S.lo; base <= S.hi; base += WAVE) {
+        const int64_t i = base + lane;
+        const bool valid = i <= S.hi;
+        const double g = valid ? S.genpos[i] : S.tg;
+        const double z = A * fabs(g - S.tg);
+        const bool in = valid && z <= S.zcut && g != S.tg;
+        const double alpha = in ? exp(-z) : 0.0;
+        const int r = valid ? (int)S.row[i] : 0;
+        const unsigned long long m = __ballot(in);
+        ns += __popcll(m);
+        for (unsigned long long mm = m; mm; mm &= mm - 1) {
+            const int l = __ffsll((long long)mm) - 1;
+            const double a_s = readlane_f64(alpha, l);
+            const int r_s = __builtin_amdgcn_readlane(r, l);
+            sum += log1p(a_s * S.Rt[(size_t)r_s * S.NP + p]);
+        }
+    }
+    if (p < S.npairs) S.T[(size_t)iA * S.npairs + p] = ns ? 2.0 * sum : NAN;
+    if (slice == 0 && lane == 0) S.ns[iA] = ns;
+}
+
 // Largest double z with exp(-z) >= 1e-8 under correct rounding of exp: bisection on the host.
 double compute_zcut() {
     double lo = 18.0, hi = 19.0;
@@ -1085,6 +1128,30 @@ int bmx_ctx_fetch_lut(bmx_ctx *c, double *psel_out, double *R_out) {
     size_t tab = (size_t)c->npairs * c->rows * sizeof(double);
     if (psel_out) HIP_TRY(hipMemcpy(psel_out, c->d_psel, tab, hipMemcpyDeviceToHost));
     if (R_out) HIP_TRY(hipMemcpy(R_out, c->d_R, tab, hipMemcpyDeviceToHost));
+    return BMX_OK;
+}
+
+int bmx_ctx_surface(bmx_ctx *c, double test_gen, int64_t win_lo, int64_t win_hi, double *T_out, int32_t *nsites_out) {
+    if (!c || !T_out) return fail(BMX_E_INVALID, "NULL argument");
+    if (!c->has_model || !c->has_sites) return fail(BMX_E_STATE, "model and sites must be set before surface");
+    HIP_TRY(hipSetDevice(c->device));
+    SurfParams S;
+    S.genpos = c->d_genpos; S.row = c->d_row; S.N = c->N; S.Rt = c->d_Rt; S.NP = c->NP; S.npairs = c->npairs;
+    S.nslices = c->nslices; S.A = c->d_A; S.nA = c->nA; S.tg = test_gen;
+    S.lo = std::max<int64_t>(win_lo, 0); S.hi = std::min<int64_t>(win_hi, c->N - 1); S.zcut = c->zcut;
+    double *dT = nullptr;
+    int32_t *dn = nullptr;
+    HIP_TRY(hipMalloc((void **)&dT, (size_t)c->nA * c->npairs * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dn, (size_t)c->nA * sizeof(int32_t)));
+    S.T = dT; S.ns = dn;
+    hipLaunchKernelGGL(surface_kernel, dim3((unsigned)(c->nA * c->nslices)), dim3(WAVE), 0, c->stream, S);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(T_out, dT, (size_t)c->nA * c->npairs * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && nsites_out) e = hipMemcpy(nsites_out, dn, (size_t)c->nA * sizeof(int32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(dT);
+    (void)hipFree(dn);
+    if (e != hipSuccess) return fail(BMX_E_HIP, std::string("surface: ") + hipGetErrorString(e));
     return BMX_OK;
 }
 

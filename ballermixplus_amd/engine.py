@@ -125,6 +125,15 @@ class Context:
         _lib.check(self._L.bmx_ctx_result_ptrs(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def surface(self, test_gen, win_lo, win_hi):
+        """T[nA, nx, nab] (NaN where the window is empty) and nsites[nA] of one test site."""
+        m = self.model
+        T = np.empty((self.nA, len(m.x), len(m.abeta)), dtype=np.float64)
+        ns = np.empty(self.nA, dtype=np.int32)
+        _lib.check(self._L.bmx_ctx_surface(self._h, float(test_gen), int(win_lo), int(win_hi), _lib.as_dp(T),
+                                           _lib.as_ip(ns)))
+        return T, ns
+
     def fetch_lut(self):
         m = self.model
         shape = (len(m.x), len(m.abeta), m.rows)

@@ -128,6 +128,13 @@ int bmx_ctx_fetch(bmx_ctx *c, double *clr, int32_t *ix, int32_t *ia, int32_t *iA
 int bmx_ctx_result_ptrs(bmx_ctx *c, void **d_clr, void **d_lin, void **d_nsites);
 /* Copy the resident tables back: psel/R as in bmx_lut_build (either may be NULL). */
 int bmx_ctx_fetch_lut(bmx_ctx *c, double *psel_out, double *R_out);
+/* Full likelihood surface of ONE test site: T_out[nA][nx][nab] = T(A, x, alpha_beta) in the grids'
+ * iteration order (NaN where the window of that A is empty -- the reference `continue`s there,
+ * BalLeRMix+_v1.py:458-459), nsites_out[nA] = window size per A (may be NULL).  The reference only
+ * keeps the maximum and lists the surfaces as future work (v1:449-450).  Computed as a plain sum of
+ * log1p(alpha*R), independently of the scan kernels' product form. */
+int bmx_ctx_surface(bmx_ctx *c, double test_gen, int64_t win_lo, int64_t win_hi, double *T_out,
+                    int32_t *nsites_out);
 /* Choose the scan kernel variant (0 = default). For A/B measurements only. */
 int bmx_ctx_set_variant(bmx_ctx *c, int variant);
 

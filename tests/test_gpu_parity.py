@@ -392,3 +392,33 @@ def test_randomised_scenarios_against_oracle(seed):
             assert got[3][t] >= 0 and ref[3][t] >= 0
             assert abs(got[0][t] - ref[0][t]) <= 1e-9 * abs(ref[0][t]) + 1e-12
     ctx.close()
+
+
+SURF = sorted(glob.glob(os.path.join(GOLD, 'surface_*.npz')))
+
+
+@pytest.mark.parametrize('path', SURF, ids=[os.path.basename(p)[8:-4] for p in SURF])
+def test_device_likelihood_surface_matches_reference(path):
+    """Every grid point, not just the maximum: T[A,x,a] from the device (bmx_ctx_surface) against the
+    reference's calcBaller called once per grid point (tests/golden/surface_*.npz), and the scan
+    kernel's maximum against the maximum of that surface."""
+    eng = _engine()
+    z = np.load(path)
+    key = 'ex1_B2' if 'ex1_B2' in os.path.basename(path) else 'ex2_B2maf_findBal'
+    argv = cases.ALL_CASES[key][0]
+    opt, case, ts = cases.host_side(argv)
+    sel = eng.NormalizedBetaBinom(case.data, case.grid, opt.nofreq, opt.MAF, opt.nosub).bind(case.neut)
+    s = int(z['site'])
+    T, ns = sel.ctx.surface(case.data.genPos[s], 0, case.data.numSites - 1)
+    ref = z['T']
+    pos = ~np.isnan(ref)                         # the reference reports a value only where T > 0
+    assert np.all((T[~pos] <= 0) | np.isnan(T[~pos]))
+    assert np.max(np.abs(T[pos] - ref[pos]) / np.abs(ref[pos])) < 1e-9
+    has = pos.any(axis=(1, 2))
+    assert np.array_equal(ns[has], z['nsites'][has])
+    clr, ix, ia, iA, n = eng.scan_batch(sel, [case.data.genPos[s]], [0], [case.data.numSites - 1])
+    flat = np.where(np.isnan(T), -np.inf, T).reshape(-1)
+    best = int(np.argmax(flat))                  # first maximum in (A, x, a) order
+    assert flat[best] > 0 and abs(clr[0] - flat[best]) <= 1e-12 * flat[best]
+    nx, nab = len(case.xs), len(case.abetas)
+    assert (int(iA[0]), int(ix[0]), int(ia[0])) == (best // (nx * nab), (best // nab) % nx, best % nab)
