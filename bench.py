@@ -144,6 +144,9 @@ def _run():
     ap.add_argument('--snps', type=int, default=1000000, help='SNPs (= windows) per GPU per step')
     ap.add_argument('--n', type=int, default=100)
     ap.add_argument('--variant', type=int, default=0)
+    ap.add_argument('--config', type=int, default=3, choices=[3, 5],
+                    help='3 (default): n=100, default 31x10x51 grid; 5: the dense-grid stress of BASELINE config 5 '
+                         '(n=200, A=100..10000 step 100, --findBal --findPos grid) on one chromosome per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-windows', type=int, default=48)
     args = ap.parse_args()
@@ -160,10 +163,15 @@ def _run():
     torch.cuda.set_device(dev)
 
     N, n = args.snps, args.n
+    if args.config == 5:
+        n = 200
     phys, gen, k, nn = synth.synth_chromosome(N, n, chrom=rank + 1)
     spect = {(a, b): f for a, b, f in synth.spect_from_counts(k, nn)}
     props = {n: 1.0}
-    grid = Grids(None, None, False, False, None, None)
+    if args.config == 5:     # --rangeA 100,10000,100 --findBal --findPos  (findBal wins: 10 x, 44 alpha)
+        grid = Grids(None, None, True, True, '100,10000,100', None)
+    else:
+        grid = Grids(None, None, False, False, None, None)
     xs, ab, As = grid.scan_order()
     model = engine.ModelArrays('B2', int(k.min()), [n], spect, props, xs, ab)
     ctx = engine.Context(dev)
@@ -232,9 +240,11 @@ def _run():
             'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE config 3: synthetic single chromosome, %d SNPs, n=%d, default '
-                                   '31x10x51 (A,x,alpha) grid, B2 scan, every SNP a test site; one chromosome '
-                                   'per GPU' % (N, n),
+            'config': {'workload': ('BASELINE config 3: synthetic single chromosome, %d SNPs, n=%d, default '
+                                    '31x10x51 (A,x,alpha) grid, B2 scan, every SNP a test site; one chromosome '
+                                    'per GPU' % (N, n)) if args.config == 3 else
+                                   ('BASELINE config 5 grid on one chromosome per GPU: %d SNPs, n=%d, A=100..10000 step 100, '
+                                    '--findBal --findPos (100x10x44), every SNP a test site' % (N, n)),
                        'windows_per_step_per_gpu': N, 'grid_points': len(As) * len(xs) * len(ab),
                        'parallelism': 'test-site sharding, dp%d, RCCL all_gather of 16-B records per step' % world.size,
                        'checksum_clr_rank0': checksum},
