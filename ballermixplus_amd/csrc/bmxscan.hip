@@ -446,7 +446,9 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                 if (m_in != 0ull) {
                     const double alpha = in ? exp_neg(z) : 0.0;
                     const int rowoff = inr ? (int)P.row[i] * WAVE : 0;
-                    spend(SP * span_generic);
+                    // factors of this pass lie in [1 - a_max, 1 + a_max*Rmax]; away from the test sites
+                    // (every alpha <= 1/2) that is [1/2, 2^span_hi], not the 54-bit worst case
+                    spend(SP * (__ballot(in && z < 0.6931471805599453) == 0ull ? max(P.span_hi, 2) : span_generic));
                     if (MODE == 1) {
                         scr_d[lane] = alpha;
                         __builtin_amdgcn_wave_barrier();

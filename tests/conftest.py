@@ -10,6 +10,12 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the in-tree library is git-ignored: build it if a fresh checkout has not run build() yet
+    so = os.path.join(REPO, 'ballermixplus_amd', 'libbmxscan.so')
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.run(['make', '-C', os.path.join(REPO, 'ballermixplus_amd', 'csrc')], check=False,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 def _has_gpu():
