@@ -58,6 +58,9 @@ PROTOTYPES = {
     'bmx_ctx_surface': (C.c_int, [_vp, C.c_double, C.c_int64, C.c_int64, _dp, _ip]),
     'bmx_input_count': (C.c_int, [C.c_char_p, _lp]),
     'bmx_input_parse': (C.c_int, [C.c_char_p, C.c_int64, C.c_int, _lp, _dp, _lp, _lp]),
+    'bmx_write_rows': (C.c_int, [C.c_char_p, C.c_int64, _lp, _dp, _dp, _ip, _ip, _ip, _ip, C.c_char_p, C.c_int,
+                                 C.c_char_p, C.c_int, C.c_char_p, C.c_int]),
+    'bmx_py_repr': (C.c_int, [C.c_double, C.c_char_p]),
 }
 
 _lib = None
@@ -121,3 +124,13 @@ def read_input(path, pos_col):
     if N:
         check(L.bmx_input_parse(path.encode(), N, int(pos_col), as_lp(phys), as_dp(coord), as_lp(k), as_lp(nn)))
     return phys, coord, k, nn
+
+
+def write_rows(path, phys, gen, clr, ix, ia, iA, ns, xs, abs_, As):
+    """Append result rows through the native writer (Python-repr-exact floats)."""
+    L = lib()
+    phys, gen, clr = i64(phys), f64(gen), f64(clr)
+    ix, ia, iA, ns = i32(ix), i32(ia), i32(iA), i32(ns)
+    pack = lambda v: b'\0'.join(s.encode() for s in v) + b'\0'
+    check(L.bmx_write_rows(path.encode(), len(phys), as_lp(phys), as_dp(gen), as_dp(clr), as_ip(ix), as_ip(ia),
+                           as_ip(iA), as_ip(ns), pack(xs), len(xs), pack(abs_), len(abs_), pack(As), len(As)))

@@ -13,6 +13,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cmath>
 #include <string>
 
 #include "../../include/bmxscan.h"
@@ -122,6 +123,128 @@ int bmx_input_parse(const char *path, int64_t N, int pos_col, int64_t *phys, dou
         return BMX_E_INVALID;
     }
     if (i != N) { bmx_set_error_("fewer data lines than announced"); return BMX_E_INVALID; }
+    return BMX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Output writer: the 7-column rows of `scores.write(f'{phys}\t{gen}\t{T}\t{x}\t{a}\t{A}\t{n}\n')`
+// (reference BalLeRMix+_v1.py:607) for integer physPos.  Floats are printed exactly as Python's
+// repr() does: shortest digits that round-trip (std::to_chars), fixed notation when the decimal
+// exponent is in [-4, 16), otherwise d.ddde+XX with at least two exponent digits.
+#include <charconv>
+#include <stdio.h>
+#include <vector>
+
+namespace {
+// appends repr(v) to out; returns new end
+char *py_repr(char *out, double v) {
+    if (v != v) { memcpy(out, "nan", 3); return out + 3; }
+    if (v == 0.0) {
+        if (std::signbit(v)) *out++ = '-';
+        memcpy(out, "0.0", 3);
+        return out + 3;
+    }
+    if (v < 0) { *out++ = '-'; v = -v; }
+    if (v > 1.7976931348623157e308) { memcpy(out, "inf", 3); return out + 3; }
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::scientific);   // d[.ddd]e[+-]XX, shortest
+    *r.ptr = 0;
+    char *e = strchr(buf, 'e');
+    int exp10 = atoi(e + 1);
+    char digits[32];
+    int nd = 0;
+    for (char *p = buf; p < e; ++p)
+        if (*p != '.') digits[nd++] = *p;
+    if (exp10 >= -4 && exp10 < 16) {          // fixed
+        if (exp10 >= 0) {
+            int i = 0;
+            for (; i <= exp10; ++i) *out++ = i < nd ? digits[i] : '0';
+            *out++ = '.';
+            if (i >= nd) *out++ = '0';
+            for (; i < nd; ++i) *out++ = digits[i];
+        } else {
+            *out++ = '0';
+            *out++ = '.';
+            for (int z = 0; z < -exp10 - 1; ++z) *out++ = '0';
+            for (int i = 0; i < nd; ++i) *out++ = digits[i];
+        }
+    } else {                                   // exponent form
+        *out++ = digits[0];
+        if (nd > 1) {
+            *out++ = '.';
+            for (int i = 1; i < nd; ++i) *out++ = digits[i];
+        }
+        *out++ = 'e';
+        *out++ = exp10 < 0 ? '-' : '+';
+        int a = exp10 < 0 ? -exp10 : exp10;
+        if (a < 10) *out++ = '0';
+        out += sprintf(out, "%d", a);
+    }
+    return out;
+}
+}  // namespace
+
+extern "C" {
+
+// repr(v) into buf (>= 32 bytes); returns its length.  Exposed for the tests.
+int bmx_py_repr(double v, char *buf) {
+    char *e = py_repr(buf, v);
+    *e = 0;
+    return (int)(e - buf);
+}
+
+// Appends M rows to `path` (opened "a"): tables are '\0'-separated, concatenated strings of the
+// grids' printed forms, in grid order.  iA[t] < 0 writes the reference's all-zero row (v1:451).
+int bmx_write_rows(const char *path, int64_t M, const int64_t *phys, const double *gen, const double *clr,
+                   const int32_t *ix, const int32_t *ia, const int32_t *iA, const int32_t *nsites,
+                   const char *xs, int nx, const char *abs_, int nab, const char *As, int nA) {
+    if (!path || (M > 0 && (!phys || !gen || !clr || !ix || !ia || !iA || !nsites)) || !xs || !abs_ || !As) {
+        bmx_set_error_("bad argument");
+        return BMX_E_INVALID;
+    }
+    auto split = [](const char *s, int n, std::vector<std::pair<const char *, int>> &v) {
+        for (int i = 0; i < n; ++i) {
+            int len = (int)strlen(s);
+            v.push_back({s, len});
+            s += len + 1;
+        }
+    };
+    std::vector<std::pair<const char *, int>> tx, ta, tA;
+    split(xs, nx, tx); split(abs_, nab, ta); split(As, nA, tA);
+    FILE *f = fopen(path, "a");
+    if (!f) { bmx_set_error_((std::string("cannot open ") + path + ": " + strerror(errno)).c_str()); return BMX_E_INVALID; }
+    std::vector<char> buf(1 << 20);
+    size_t used = 0;
+    for (int64_t t = 0; t < M; ++t) {
+        if (used + 512 > buf.size()) { fwrite(buf.data(), 1, used, f); used = 0; }
+        char *o = buf.data() + used;
+        o += sprintf(o, "%lld\t", (long long)phys[t]);
+        o = py_repr(o, gen[t]);
+        if (iA[t] < 0) {
+            memcpy(o, "\t0.0\t0.0\t0.0\t0.0\t0.0\n", 21);
+            o += 21;
+        } else {
+            if (ix[t] < 0 || ix[t] >= nx || ia[t] < 0 || ia[t] >= nab || iA[t] >= nA) {
+                fclose(f);
+                bmx_set_error_("grid index out of range");
+                return BMX_E_INVALID;
+            }
+            *o++ = '\t';
+            o = py_repr(o, clr[t]);
+            *o++ = '\t';
+            memcpy(o, tx[ix[t]].first, tx[ix[t]].second); o += tx[ix[t]].second;
+            *o++ = '\t';
+            memcpy(o, ta[ia[t]].first, ta[ia[t]].second); o += ta[ia[t]].second;
+            *o++ = '\t';
+            memcpy(o, tA[iA[t]].first, tA[iA[t]].second); o += tA[iA[t]].second;
+            o += sprintf(o, "\t%d\n", nsites[t]);
+        }
+        used = (size_t)(o - buf.data());
+    }
+    if (used) fwrite(buf.data(), 1, used, f);
+    if (fclose(f) != 0) { bmx_set_error_("write failed"); return BMX_E_INVALID; }
     return BMX_OK;
 }
 

@@ -148,6 +148,17 @@ int bmx_input_count(const char *path, int64_t *n_out);
 int bmx_input_parse(const char *path, int64_t N, int pos_col, int64_t *phys, double *coord,
                     int64_t *k, int64_t *n);
 
+/* ---- output (host only) ------------------------------------- */
+/* Appends M result rows to `path` in the reference's format (BalLeRMix+_v1.py:607), floats printed
+ * exactly as Python's repr().  xs/abs/As: the grids' printed forms, '\0'-separated, in grid order.
+ * iA[t] < 0 writes the all-zero row (v1:451).  Integer physPos only (the --noCenter mode prints a
+ * float there and stays in Python). */
+int bmx_write_rows(const char *path, int64_t M, const int64_t *phys, const double *gen, const double *clr,
+                   const int32_t *ix, const int32_t *ia, const int32_t *iA, const int32_t *nsites,
+                   const char *xs, int nx, const char *abs_, int nab, const char *As, int nA);
+/* repr(v) as Python prints it, into buf (>= 32 bytes); returns the length. */
+int bmx_py_repr(double v, char *buf);
+
 #ifdef __cplusplus
 }
 #endif

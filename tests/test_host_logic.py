@@ -157,3 +157,53 @@ def test_native_reader_edge_cases(tmp_path):
         _lib.read_input(str(f), 1)
     with pytest.raises(_lib.BmxError):
         _lib.read_input(str(tmp_path / 'missing.txt'), 1)
+
+
+def test_native_float_formatting_equals_python_repr():
+    """bmx_py_repr (used by the native row writer) vs repr(): fixed/exponent switch, shortest digits."""
+    import ctypes as C
+    import random
+    import struct
+    from ballermixplus_amd import _lib
+    L = _lib.lib()
+    buf = C.create_string_buffer(64)
+
+    def r(v):
+        L.bmx_py_repr(v, buf)
+        return buf.value.decode()
+    fixed = [0.0, -0.0, 1.0, 100.0, 1e16, 1e15, 9999999999999998.0, 1.2e-07, 1e-4, 0.0001234, 1e-5, 0.1 + 0.2,
+             31.21810547602786, 1e22, 1.7976931348623157e308, 5e-324, 2.2250738585072014e-308,
+             123456789012345680.0, 0.05, 0.15000000000000002, 1000000000.0, -3.5e-10, 0.006999999999999999]
+    for v in fixed:
+        assert r(v) == repr(v), v
+    rng = random.Random(3)
+    for i in range(40000):
+        v = struct.unpack('<d', struct.pack('<Q', rng.getrandbits(64)))[0] if i % 2 else rng.random() * 10.0 ** rng.randint(-12, 20)
+        if v == v and abs(v) != float('inf'):
+            assert r(v) == repr(v), v
+
+
+def test_native_row_writer_writes_the_same_bytes(tmp_path):
+    from ballermixplus_amd import _lib, scan as scanmod
+    d = InputData(os.path.join(REFT, 'Example2_balancing_10MYA_DAF.txt'))
+    ts = scanmod.sites_alpha(d, 1)
+    g = Grids(None, None, False, False, None, None)
+
+    class S:
+        grid_x, grid_abeta, grid_A = g.scan_order()
+    N = len(ts)
+    rg = np.random.default_rng(2)
+    res = (rg.random(N) * 10.0 ** rg.integers(-7, 5, N), rg.integers(0, 10, N).astype(np.int32),
+           rg.integers(0, 51, N).astype(np.int32), rg.integers(-1, 31, N).astype(np.int32),
+           rg.integers(1, 5000, N).astype(np.int32))
+    a, b = tmp_path / 'native.txt', tmp_path / 'python.txt'
+    scanmod.write_rows(str(a), ts, res, S)
+    keep = _lib.write_rows
+    try:
+        _lib.write_rows = lambda *x, **k: (_ for _ in ()).throw(ImportError())
+        scanmod.write_rows(str(b), ts, res, S)
+    finally:
+        _lib.write_rows = keep
+    assert a.read_bytes() == b.read_bytes()
+    rows = a.read_text().splitlines()
+    assert rows[0] == 'physPos\tgenPos\tCLR\tx_hat\ts_hat\tA_hat\tnSites' and len(rows) == N + 1
