@@ -143,6 +143,9 @@ def _run():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--snps', type=int, default=1000000, help='SNPs (= windows) per GPU per step')
     ap.add_argument('--n', type=int, default=100)
+    ap.add_argument('--n-spread', type=int, default=0,
+                    help='>0: sample sizes n-spread..n drawn per site (missing data): LUT rows = sum(n_i+1), which '
+                         'can exceed LDS and exercises the R-from-L2 path')
     ap.add_argument('--variant', type=int, default=0)
     ap.add_argument('--config', type=int, default=3, choices=[3, 5],
                     help='3 (default): n=100, default 31x10x51 grid; 5: the dense-grid stress of BASELINE config 5 '
@@ -166,14 +169,21 @@ def _run():
     if args.config == 5:
         n = 200
     phys, gen, k, nn = synth.synth_chromosome(N, n, chrom=rank + 1)
+    sizes = [n]
+    if args.n_spread > 0:      # thin the sample sizes: n_i uniform in [n - spread, n], counts rescaled
+        rng = np.random.default_rng(77 + rank)
+        n2 = rng.integers(n - args.n_spread, n + 1, N)
+        k = np.where(k == nn, n2, np.maximum(1, np.minimum(n2 - 1, (k * n2) // nn)))
+        nn = n2
+        sizes = sorted(set(nn.tolist()))
     spect = {(a, b): f for a, b, f in synth.spect_from_counts(k, nn)}
-    props = {n: 1.0}
+    props = {int(s_): float(sum(f for (a, b), f in spect.items() if b == s_)) for s_ in sizes}
     if args.config == 5:     # --rangeA 100,10000,100 --findBal --findPos  (findBal wins: 10 x, 44 alpha)
         grid = Grids(None, None, True, True, '100,10000,100', None)
     else:
         grid = Grids(None, None, False, False, None, None)
     xs, ab, As = grid.scan_order()
-    model = engine.ModelArrays('B2', int(k.min()), [n], spect, props, xs, ab)
+    model = engine.ModelArrays('B2', int(k.min()), sizes, spect, props, xs, ab)
     ctx = engine.Context(dev)
     ctx.set_variant(args.variant)
     ctx.set_model(model, As)
