@@ -50,18 +50,26 @@ def test_rangeA_implements_the_evident_intent():
     ('spect_ex2_DAF_nosub.txt', 'Example2_balancing_10MYA_DAF.txt', dict(MAF=False, nosub=True)),
     ('spect_ex2_MAF_nosub.txt', 'Example2_balancing_10MYA_MAF.txt', dict(MAF=True, nosub=True)),
 ])
-def test_getSpect_is_byte_identical(tmp_path, out, inp, kw):
+def test_getSpect_is_byte_identical(tmp_path, out, inp, kw, monkeypatch):
     dst = tmp_path / out
-    helpers.getSpect(os.path.join(REFT, inp), str(dst), kw['MAF'], kw['nosub'])
+    helpers.getSpect(os.path.join(REFT, inp), str(dst), kw['MAF'], kw['nosub'])          # vectorised path
     assert filecmp.cmp(str(dst), os.path.join(GOLD, 'helpers', out), shallow=False)
+    monkeypatch.setattr(helpers, '_columns', lambda f: None)                              # reference-style text loop
+    dst2 = tmp_path / ('loop_' + out)
+    helpers.getSpect(os.path.join(REFT, inp), str(dst2), kw['MAF'], kw['nosub'])
+    assert filecmp.cmp(str(dst2), os.path.join(GOLD, 'helpers', out), shallow=False)
 
 
 @pytest.mark.parametrize('out,inp', [('config_ex1.txt', 'Example1_fullSweep_200kya_DAF.txt'),
                                      ('config_ex2.txt', 'Example2_balancing_10MYA_DAF.txt')])
-def test_getConfig_is_byte_identical(tmp_path, out, inp):
+def test_getConfig_is_byte_identical(tmp_path, out, inp, monkeypatch):
     dst = tmp_path / out
     helpers.getConfig(os.path.join(REFT, inp), str(dst))
     assert filecmp.cmp(str(dst), os.path.join(GOLD, 'helpers', out), shallow=False)
+    monkeypatch.setattr(helpers, '_columns', lambda f: None)
+    dst2 = tmp_path / ('loop_' + out)
+    helpers.getConfig(os.path.join(REFT, inp), str(dst2))
+    assert filecmp.cmp(str(dst2), os.path.join(GOLD, 'helpers', out), shallow=False)
 
 
 def test_input_parsing_semantics():
