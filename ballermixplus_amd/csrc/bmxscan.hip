@@ -358,10 +358,12 @@ struct alignas(16) ScratchEnt {
     int pad;
 };
 
-template <int J, bool USE_LDS, int MODE>
+template <int J, bool USE_LDS, int MODE_>
 __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(ScanParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then scratch
     constexpr int SP = WAVE / J;                                    // sites per generic pass
+    constexpr bool QUAD = (MODE_ == 2);                             // MODE_ 2 = MODE 1 + quads in far passes
+    constexpr int MODE = MODE_ ? 1 : 0;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x >> 6;
     const int slice = blockIdx.x % P.nslices;
@@ -515,6 +517,36 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             scr[lane] = ScratchEnt{Ev, rowoff, 0};
                             __builtin_amdgcn_wave_barrier();
                             constexpr int BS = J >= 16 ? 4 : 8;        // sites per unrolled block
+                            // Far passes (every alpha <= 1/2: factors >= 1/2, the expanded product is well
+                            // conditioned) can take FOUR sites per step:
+                            //   prod_m (1 + F v_m) = 1 + F e1 + F^2 e2 + F^3 e3 + F^4 e4   (Horner in F),
+                            // e_k = elementary symmetric polynomials of v_1..v_4 shared by all J test sites:
+                            // 4 FMA + 1 MUL per test site per four sites.
+                            if (QUAD && lowbits <= 2) {
+                                for (int l0 = 0; l0 < cnt; l0 += 4) {
+                                    spend(span8 / 2);
+                                    double v[4];
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        const ScratchEnt en = scr[l0 + u];
+                                        v[u] = en.e * loadR(en.ro);
+                                    }
+                                    const double s01 = v[0] + v[1], q01 = v[0] * v[1];
+                                    const double s23 = v[2] + v[3], q23 = v[2] * v[3];
+                                    const double e1 = s01 + s23;
+                                    const double e2 = fma(s01, s23, q01 + q23);
+                                    const double e3 = fma(q01, s23, q23 * s01);
+                                    const double e4 = q01 * q23;
+#pragma unroll
+                                    for (int j = 0; j < J; ++j) {
+                                        double t = fma(F[j], e4, e3);
+                                        t = fma(F[j], t, e2);
+                                        t = fma(F[j], t, e1);
+                                        acc[j] *= fma(F[j], t, 1.0);
+                                        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 8 chains in flight
+                                    }
+                                }
+                            } else
                             for (int l0 = 0; l0 < cnt; l0 += BS) {
                                 spend(span8 * BS / 8);
                                 double v[BS];
@@ -1042,11 +1074,11 @@ int bmx_ctx_scan(bmx_ctx *c) {
     // (-s far larger than 1) is better served one test site per wave
     const bool can_group = c->tests_sorted && c->tests_dense && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
     int J = 0;
-    // variants: 0 -> J=16 pair/LDS-broadcast (default); 3 -> J=8, 4 -> J=4 (same mode);
-    //           5/6/7 -> J=16/8/4 with the readlane single-site inner loop; 1, 2 -> per-site kernel
+    // variants (A/B runs): 0 -> J=16, pairs near / quads far (default); 3 -> J=8, 4 -> J=4 (same form);
+    //           8/9 -> J=16/8 pairs only; 5/6/7 -> J=16/8/4 readlane single-site loop; 1, 2 -> per-site kernel
     if (can_group) {
         const int v = c->variant;
-        J = (v == 0 || v == 5) ? 16 : (v == 3 || v == 6) ? 8 : (v == 4 || v == 7) ? 4 : 0;
+        J = (v == 0 || v == 5 || v == 8) ? 16 : (v == 3 || v == 6 || v == 9) ? 8 : (v == 4 || v == 7) ? 4 : 0;
     }
     P.sites_per_block = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : 4);
     if (J == 16 && P.sites_per_block < 64) P.sites_per_block = 64;
@@ -1058,13 +1090,16 @@ int bmx_ctx_scan(bmx_ctx *c) {
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     const void *fn = nullptr;
 #define PICK(K) (use_lds ? (const void *)K<true> : (const void *)K<false>)
-    const int mode = (c->variant >= 5 && c->variant <= 7) ? 0 : 1;
-#define GPICK(JJ) (mode ? (use_lds ? (const void *)clr_scan_grouped_kernel<JJ, true, 1> : (const void *)clr_scan_grouped_kernel<JJ, false, 1>) \
-                        : (use_lds ? (const void *)clr_scan_grouped_kernel<JJ, true, 0> : (const void *)clr_scan_grouped_kernel<JJ, false, 0>))
+    // inner-loop form: 0 readlane / one site per step; 1 LDS broadcast + pairs; 2 (default) = 1 + four
+    // sites per step in far passes
+    const int mode = (c->variant >= 5 && c->variant <= 7) ? 0 : (c->variant >= 8 && c->variant <= 9) ? 1 : 2;
+#define GP2(JJ, MM) (use_lds ? (const void *)clr_scan_grouped_kernel<JJ, true, MM> : (const void *)clr_scan_grouped_kernel<JJ, false, MM>)
+#define GPICK(JJ) (mode == 2 ? GP2(JJ, 2) : mode == 1 ? GP2(JJ, 1) : GP2(JJ, 0))
     if (J == 8) fn = GPICK(8);
     else if (J == 16) fn = GPICK(16);
     else if (J == 4) fn = GPICK(4);
     else fn = PICK(clr_scan_kernel);
+#undef GP2
 #undef GPICK
 #undef PICK
     // One wave per SIMD issues FP64 at half rate (measured), so a workgroup whose LDS footprint

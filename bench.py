@@ -23,10 +23,12 @@ sys.path.insert(0, REPO)
 
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6300 achievable)
-# executed FP64 flop per evaluation (one site x one grid pair x one test site) in the default kernel:
-# bulk sites go two at a time, (1+F v1)(1+F v2) = 1 + F*(s + F*q): 2 FMA + 1 MUL = 5 flop per pair and
-# test site, plus v1, v2, s, q (4 flop) shared by the J = 16 test sites of a group: 2.5 + 4/32 = 2.625
-FLOP_PER_EVAL = 2.625
+# executed FP64 flop per evaluation (one site x one grid pair x one test site) in the default kernel.
+# 98 % of the bulk sites are in "far" passes and go four at a time:
+#   prod_m (1 + F v_m) = 1 + F(e1 + F(e2 + F(e3 + F e4))): 4 FMA + 1 MUL = 9 flop per test site per four sites,
+#   plus v_1..v_4 and e_1..e_4 (16 flop) shared by the J = 16 test sites of a group: 9/4 + 16/64 = 2.5
+# (near passes use pairs, 2.625; generic passes 3 -- both a few % of the sites).
+FLOP_PER_EVAL = 2.5
 SURVEY_FLOP_PER_EVAL = 32        # SURVEY.md 8(d) convention for the reference's FMA + log1p form
 
 
@@ -259,17 +261,17 @@ def _run():
                        'parallelism': 'test-site sharding, dp%d, RCCL all_gather of 16-B records per step' % world.size,
                        'checksum_clr_rank0': checksum},
             'roofline': {
-                'bound': 'valu_fp64', 'kernel': 'clr_scan_grouped_kernel<16,true,1>',
+                'bound': 'valu_fp64', 'kernel': 'clr_scan_grouped_kernel<16,true,2>',
                 'achieved': evals_s * FLOP_PER_EVAL / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': evals_s * FLOP_PER_EVAL / 1e12 / FP64_VALU_PEAK_TFLOPS, 'traffic': None,
                 'kernel_ms': k_ms, 'evals_per_launch': evals_per_step, 'evals_per_s': evals_s,
                 'flop_per_eval_executed': FLOP_PER_EVAL,
                 'survey_convention_tflops': evals_s * SURVEY_FLOP_PER_EVAL / 1e12,
-                'note': 'lanes multiply (1+alpha*R) instead of summing log1p, two sites per step: 2 FMA + 1 MUL '
-                        'per test site per pair of sites; peak = vector FP64 (no contraction exists in this path, '
+                'note': 'lanes multiply (1+alpha*R) instead of summing log1p, four sites per step: 4 FMA + 1 MUL '
+                        'per test site per four sites; peak = vector FP64 (no contraction exists in this path, '
                         'so not MFMA); survey_convention = SURVEY 8(d) "1 evaluation = 32 flop"'},
             'roofline_hbm': {
-                'bound': 'hbm', 'kernel': 'clr_scan_grouped_kernel<16,true,1>',
+                'bound': 'hbm', 'kernel': 'clr_scan_grouped_kernel<16,true,2>',
                 'achieved': bytes_per_step / (k_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': bytes_per_step / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                 'algorithmic_bytes_per_launch': bytes_per_step},

@@ -378,7 +378,7 @@ def test_randomised_scenarios_against_oracle(seed):
         if mode == 3:
             hi = np.maximum(hi - rng.integers(0, 2 * r, M), 0)
     ref = c_scan(L, Rfin, As, gen, rows, tg, lo, hi)
-    for variant in (0, 2, 3):
+    for variant in (0, 2, 3, 8):
         ctx.set_variant(variant)
         ctx.set_tests(tg, lo, hi)
         ctx.scan()
