@@ -67,6 +67,12 @@ def sites_site_based(data, r, s):
     """_siteBased, v1:580-594: r sites to the left, r+1 to the right (end inclusive)."""
     ts = TestSites()
     N = data.numSites
+    if float(s) == int(s) and int(s) >= 1 and float(r) == int(r):      # the usual case, vectorised
+        idx = np.arange(0, N, int(s))
+        g = data.genPos[idx].tolist()
+        ts.add_many(data.position[idx].tolist(), g, g, np.maximum(0, idx - int(r)).tolist(),
+                    np.minimum(N - 1, idx + int(r) + 1).tolist())
+        return ts
     i = 0
     while i < N:
         start_i = max(0, i - r)
@@ -78,10 +84,26 @@ def sites_site_based(data, r, s):
 
 
 def sites_fix_center(data, w, s):
-    """_fixSize_siteCenter, v1:549-577: w-nt window centred on every int(s)-th site."""
+    """_fixSize_siteCenter, v1:549-577: w-nt window centred on every int(s)-th site.  The
+    reference's two monotone pointers are `first index with position >= bound`, i.e. searchsorted."""
     ts = TestSites()
     N = data.numSites
-    pos = data.position
+    pos = np.asarray(data.position)
+    if N and int(s) >= 1 and np.all(pos[1:] >= pos[:-1]):
+        idx = np.arange(0, N, int(s))
+        test = pos[idx]
+        start = np.maximum(0, test - w / 2)
+        end = np.minimum(test + w / 2, pos[-1])
+        posf = pos.astype(np.float64)
+        start_i = np.searchsorted(posf, start, 'left')
+        end_i = np.minimum(np.searchsorted(posf, end, 'left'), N - 1)
+        if np.any(end_i < start_i):
+            j = int(np.nonzero(end_i < start_i)[0][0])
+            print(start[j], start_i[j], end[j], end_i[j])
+            sys.exit(1)
+        g = data.genPos[idx].tolist()
+        ts.add_many(test.tolist(), g, g, start_i.tolist(), end_i.tolist())
+        return ts
     i = 0
     start_i = 0
     end_i = 0

@@ -215,3 +215,47 @@ def test_native_row_writer_writes_the_same_bytes(tmp_path):
     assert a.read_bytes() == b.read_bytes()
     rows = a.read_text().splitlines()
     assert rows[0] == 'physPos\tgenPos\tCLR\tx_hat\ts_hat\tA_hat\tnSites' and len(rows) == N + 1
+
+
+def test_vectorised_window_generation_equals_the_reference_loops(monkeypatch):
+    """sites_site_based / sites_fix_center fast paths vs the reference's per-site loops."""
+    from ballermixplus_amd import scan as scanmod
+    p = InputData(os.path.join(REFT, 'Example2_balancing_10MYA_DAF.txt'), phys=True)
+
+    def loop_site_based(data, r, s):
+        out = []
+        i = 0
+        while i < data.numSites:
+            w = np.arange(max(0, i - r), min(data.numSites - 1, i + r + 1) + 1, dtype=int)
+            out.append((int(i), int(w[0]), int(w[-1])))
+            i += s
+        return out
+
+    def loop_fix_center(data, w, s):
+        out = []
+        pos = data.position
+        i = start_i = end_i = 0
+        while i < data.numSites:
+            start = max(0, pos[i] - w / 2)
+            end = min(pos[i] + w / 2, pos[-1])
+            while pos[start_i] < start:
+                start_i += 1
+            while end_i < data.numSites:
+                if pos[end_i] < end:
+                    end_i += 1
+                else:
+                    break
+            end_i = min(end_i, data.numSites - 1)
+            out.append((int(i), int(start_i), int(end_i)))
+            i += int(s)
+        return out
+
+    for r, s in [(50, 25.0), (3, 1), (400, 7.0), (2000, 100.0)]:
+        ts = scanmod.sites_site_based(p, r, s)
+        ref = loop_site_based(p, r, s)
+        assert [(a, b) for a, b in zip(ts.lo, ts.hi)] == [(b, c) for _, b, c in ref]
+        assert ts.test_gen == [float(p.genPos[i]) for i, _, _ in ref]
+    for w, s in [(1000.0, 2.0), (5000.0, 40.0), (10.0, 1), (1e7, 13.0)]:
+        ts = scanmod.sites_fix_center(p, w, s)
+        ref = loop_fix_center(p, w, s)
+        assert [(a, b) for a, b in zip(ts.lo, ts.hi)] == [(b, c) for _, b, c in ref]
