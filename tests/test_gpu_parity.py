@@ -422,3 +422,50 @@ def test_device_likelihood_surface_matches_reference(path):
     assert flat[best] > 0 and abs(clr[0] - flat[best]) <= 1e-12 * flat[best]
     nx, nab = len(case.xs), len(case.abetas)
     assert (int(iA[0]), int(ix[0]), int(ia[0])) == (best // (nx * nab), (best // nab) % nx, best % nab)
+
+
+def test_fallback_paths_extreme_table_and_unsorted_tests():
+    """(i) A neutral probability of 1e-25 makes R ~ 1e24: too wide for block-wise exponent extraction,
+    the library must fall back to the per-site kernel and still agree with the oracle;
+    (ii) test positions given in descending order (not what any Scan mode produces, but the ABI
+    allows it) must give the same rows as the ascending call."""
+    eng = _engine()
+    L = c_oracle()
+    from ballermixplus_amd.hostmodel import Grids
+    rng = np.random.default_rng(9)
+    N, n = 2500, 30
+    gen = np.cumsum(rng.geometric(0.3, N)) * 2e-6
+    k = rng.integers(1, n + 1, N)
+    k[::50] = 7
+    nn = np.full(N, n)
+    cnt = {}
+    for a in k.tolist():
+        cnt[(a, n)] = cnt.get((a, n), 0) + 1
+    spect = {key: v / N for key, v in cnt.items()}
+    spect[(7, n)] = 1e-25                                  # (checksum of the helper file is not the library's business)
+    grid = Grids(None, None, False, False, None, '200,1000,5000')
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays('B2', 1, [n], spect, {n: 1.0}, xs, ab)
+    rows = model.rows_of(k, nn)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, rows)
+    _, R = ctx.fetch_lut()
+    assert np.nanmax(R) > 1e20
+    Rfin = np.where(np.isfinite(R), R, 0.0)
+    idx = np.arange(0, N, 2)
+    lo, hi = np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64)
+    ref = c_scan(L, Rfin, As, gen, rows, gen[idx], lo, hi)
+    ctx.set_tests(gen[idx], lo, hi)
+    ctx.scan()
+    got = ctx.fetch()
+    for f in (1, 2, 3, 4):
+        assert np.array_equal(got[f], ref[f])
+    assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-12)
+    # (ii) descending test order
+    ctx.set_tests(gen[idx][::-1].copy(), lo, hi)
+    ctx.scan()
+    rev = ctx.fetch()
+    for a, b in zip(got, rev):
+        assert np.array_equal(a, b[::-1])
+    ctx.close()
