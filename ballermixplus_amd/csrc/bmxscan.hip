@@ -188,7 +188,7 @@ struct ScanParams {
     int span_hi;       // grouped kernel: bits by which one factor 1+alpha*R can exceed 1 (>= 1)
     double rmax;       // max(0, largest finite R of the table)
     int sites_per_block;
-    double *part_T;    // [M][nslices]
+    double *part_T;    // [nslices][M]
     int32_t *part_lin;
     int32_t *part_ns;
 };
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_kernel(ScanParams P) {
             }
         }
         if (lane == 0) {
-            const size_t o = (size_t)t * P.nslices + slice;
+            const size_t o = (size_t)slice * P.M + t;          // [slice][M]: coalesced for writer and reader
             P.part_T[o] = bestT;
             P.part_lin[o] = bestLin;
             P.part_ns[o] = bestNs;
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                 if (oT > bT || (oT == bT && oL < bL)) { bT = oT; bL = oL; }
             }
             if (lane == 0 && j < nvalid) {
-                const size_t o = (size_t)(tb + j) * P.nslices + slice;
+                const size_t o = (size_t)slice * P.M + (tb + j);   // [slice][M]
                 P.part_T[o] = bT;
                 P.part_lin[o] = bL;
                 P.part_ns[o] = 0;
@@ -643,12 +643,12 @@ __global__ void finalize_kernel(FinalParams F) {
     double bT = 0.0;
     int bL = 0x7fffffff, bN = 0;
     for (int s = 0; s < F.nslices; ++s) {
-        const double T = F.part_T[t * F.nslices + s];
-        const int L = F.part_lin[t * F.nslices + s];
+        const double T = F.part_T[(size_t)s * F.M + t];
+        const int L = F.part_lin[(size_t)s * F.M + t];
         if (T > bT || (T == bT && L < bL)) {
             bT = T;
             bL = L;
-            bN = F.part_ns[t * F.nslices + s];
+            bN = F.part_ns[(size_t)s * F.M + t];
         }
     }
     const bool none = (bL == 0x7fffffff);
