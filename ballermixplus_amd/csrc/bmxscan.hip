@@ -341,17 +341,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_kernel(ScanParams P) {
 //
 // The argmax is tracked per lane on (binary exponent, mantissa) of the product -- an exact
 // ordering that needs no logarithm; one log per test site is taken at the very end.
-template <int J>
-struct GroupMeta {
-    double tj;   // test position of this lane's j
-    int lo, hi;  // its inclusive window, empty (1,0) for j beyond the last test site
-};
-
-// MODE 0: (E_i, row_i) and alpha_ij reach the lanes by v_readlane, one site per step.
-// MODE 1: they are staged in a wave-private LDS scratch and read back with uniform-address
-//         (broadcast) ds_read_b128, and bulk sites are taken two at a time:
-//             (1 + F v1)(1 + F v2) = 1 + F*(s + F*q),   s = v1 + v2,  q = v1*v2
-//         i.e. 2 FMA + 1 MUL per test site per PAIR of sites (s, q shared by all J test sites).
+//
+// Inner-loop forms (template parameter MODE_; 2 is what ships, 0 and 1 stay for A/B runs):
+//   0: (E_i, row_i) and alpha_ij reach the lanes by v_readlane, one site per step.
+//   1: they are staged in a wave-private LDS scratch and read back with uniform-address
+//      (broadcast) ds_read, and bulk sites are taken two at a time:
+//          (1 + F v1)(1 + F v2) = 1 + F*(s + F*q),   s = v1 + v2,  q = v1*v2
+//      i.e. 2 FMA + 1 MUL per test site per PAIR of sites (s, q shared by all J test sites).
+//   2: as 1, and passes whose every alpha is <= 1/2 take FOUR sites per step (see the bulk loop).
+// Measured on gfx950 (profiles/): every VALU instruction of this kernel -- FP64 or not -- costs
+// ~4.5 SIMD cycles at 2 waves/SIMD and ~10 at one, so the design minimises instruction count:
+// 1.98 VALU instructions per 64 evaluations in form 2 at J = 16, vs ~6 in the per-site kernel.
 struct alignas(16) ScratchEnt {
     double e;
     int ro;   // row * 64
