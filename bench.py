@@ -276,7 +276,7 @@ def _run():
                 'frac': bytes_per_step / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                 'algorithmic_bytes_per_launch': bytes_per_step},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world.size == 1:      # reported baseline: rank 0, N = 1 only
             res['cpu_baseline'] = cpu_baseline(gen, k, nn, spect, props, grid, args.cpu_windows, 256)
         line = json.dumps(res)
     else:
