@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/bmxscan.h"
@@ -918,8 +919,12 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     std::vector<uint64_t> px;
     std::vector<double> py;
     {
+        std::unordered_set<uint64_t> seen;        // many (k, n) give the same argument bits: check each once
         auto consider = [&](double v) {
             if (!(v >= 13.0) || !(v < 1e300)) return;     // lgam's log(x) branch starts at 13
+            uint64_t vb;
+            memcpy(&vb, &v, sizeof(vb));
+            if (!seen.insert(vb).second) return;
             const double hl = log(v);
             if (hl != bmx::crlog(v)) {
                 uint64_t b;
