@@ -85,10 +85,10 @@ struct LutParams {
 // inside nested loops: the pmf body is large, and gfx950 device-function calls from a partially
 // active wave proved unusable here (hang), so nothing in this kernel is an out-of-line call.
 __global__ void bb_lut_kernel(LutParams P) {
-    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int npairs = P.nx * P.nab;
-    if (gid >= npairs * P.rows) return;
-    int p = gid / P.rows, r = gid % P.rows;
+    if (gid >= (int64_t)npairs * P.rows) return;
+    int p = (int)(gid / P.rows), r = (int)(gid % P.rows);
     int ix = p / P.nab, ia = p % P.nab;
     int j = 0;
     while (j + 1 < P.n_sizes && r >= P.row_off[j + 1]) j++;
@@ -169,10 +169,18 @@ __global__ void locate_kernel(const double *genpos, int64_t N, const double *tes
     center_hi[t] = a;  // first index with genpos > test position (sites in between are ties)
 }
 
+// LUT row of a site: 2 bytes per site normally (<= 65535 rows), 4 when the table is larger
+// (hundreds of distinct sample sizes).
+struct RowArray {
+    const uint16_t *r16;
+    const uint32_t *r32;
+    __device__ __forceinline__ int operator[](int64_t i) const { return r32 ? (int)r32[i] : (int)r16[i]; }
+};
+
 // ----------------------------------------------------------------------------- K2
 struct ScanParams {
     const double *genpos;
-    const uint16_t *row;
+    RowArray row;
     int64_t N;
     const double *Rt;  // [rows][NP]
     int rows, NP, npairs, nslices;
@@ -684,7 +692,7 @@ __global__ void finalize_kernel(FinalParams F) {
 // kernels -- a plain sum of log1p(alpha*R) per (A, pair) -- so that it doubles as an on-device
 // cross-check of the product form.  One workgroup per (A, 64-pair slice); lanes = pairs.
 struct SurfParams {
-    const double *genpos; const uint16_t *row; int64_t N;
+    const double *genpos; RowArray row; int64_t N;
     const double *Rt; int NP, npairs, nslices;
     const double *A; int nA;
     double tg; int64_t lo, hi;
@@ -763,7 +771,8 @@ struct bmx_ctx {
     bool has_sites = false;
     int64_t N = 0;
     double *d_genpos = nullptr;
-    uint16_t *d_row = nullptr;
+    uint16_t *d_row = nullptr;      // one of the two is used
+    uint32_t *d_row32 = nullptr;
     // tests
     bool has_tests = false;
     int64_t M = 0;
@@ -787,7 +796,7 @@ void free_model(bmx_ctx *c) {
     c->has_model = false;
 }
 void free_sites(bmx_ctx *c) {
-    dfree(c->d_genpos); dfree(c->d_row);
+    dfree(c->d_genpos); dfree(c->d_row); dfree(c->d_row32);
     c->has_sites = false;
 }
 void free_tests(bmx_ctx *c) {
@@ -817,7 +826,7 @@ int validate_model(const bmx_model *m) {
         if (m->sizes[j] < 1 || m->row_off[j + 1] - m->row_off[j] != want)
             return fail(BMX_E_INVALID, "model: row_off does not match sizes (n+1 rows per size, 2 for B1)");
     }
-    if (m->row_off[m->n_sizes] > 65535) return fail(BMX_E_LIMIT, "model: more than 65535 LUT rows");
+    if (m->row_off[m->n_sizes] > (1 << 24)) return fail(BMX_E_LIMIT, "model: more than 2^24 LUT rows");
     for (int i = 0; i < m->nx; i++)
         if (!(m->x[i] > 0.0 && m->x[i] < 1.0)) return fail(BMX_E_INVALID, "model: x grid must lie in (0,1)");
     for (int i = 0; i < m->nab; i++)
@@ -995,21 +1004,27 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
     if (!c->has_model) return fail(BMX_E_STATE, "set_model must precede set_sites");
     if (N < 1 || !genpos || !row) return fail(BMX_E_INVALID, "empty site arrays");
-    std::vector<uint16_t> r16((size_t)N);
+    const bool wide = c->rows > 65535;
+    std::vector<uint16_t> r16(wide ? 0 : (size_t)N);
+    std::vector<uint32_t> r32(wide ? (size_t)N : 0);
     for (int64_t i = 0; i < N; i++) {
         if (row[i] < 0 || row[i] >= c->rows) return fail(BMX_E_INVALID, "site row index outside the LUT");
         if (!(c->h_g[(size_t)row[i]] > 0.0))
             return fail(BMX_E_INVALID, "a site has a (count, sample size) whose neutral probability is missing or not positive");
         if (i && genpos[i] < genpos[i - 1]) return fail(BMX_E_INVALID, "genetic positions must be non-decreasing");
         if (!(genpos[i] == genpos[i])) return fail(BMX_E_INVALID, "NaN genetic position");
-        r16[(size_t)i] = (uint16_t)row[i];
+        if (wide) r32[(size_t)i] = (uint32_t)row[i]; else r16[(size_t)i] = (uint16_t)row[i];
     }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_sites(c);
     int rc;
     if ((rc = upload(c->d_genpos, genpos, (size_t)N, c->stream))) return rc;
-    if ((rc = upload(c->d_row, (const uint16_t *)r16.data(), (size_t)N, c->stream))) return rc;
+    if (wide) {
+        if ((rc = upload(c->d_row32, (const uint32_t *)r32.data(), (size_t)N, c->stream))) return rc;
+    } else {
+        if ((rc = upload(c->d_row, (const uint16_t *)r16.data(), (size_t)N, c->stream))) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->N = N;
     c->has_sites = true;
@@ -1067,7 +1082,7 @@ int bmx_ctx_scan(bmx_ctx *c) {
     if (!c->has_model || !c->has_sites || !c->has_tests) return fail(BMX_E_STATE, "model, sites and tests must be set before scan");
     HIP_TRY(hipSetDevice(c->device));
     ScanParams P;
-    P.genpos = c->d_genpos; P.row = c->d_row; P.N = c->N; P.Rt = c->d_Rt;
+    P.genpos = c->d_genpos; P.row = RowArray{c->d_row, c->d_row32}; P.N = c->N; P.Rt = c->d_Rt;
     P.rows = c->rows; P.NP = c->NP; P.npairs = c->npairs; P.nslices = c->nslices;
     P.A = c->d_A; P.nA = c->nA; P.test_gen = c->d_test_gen; P.win_lo = c->d_win_lo; P.win_hi = c->d_win_hi;
     P.center = c->d_center; P.center_hi = c->d_center_hi; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi; P.rmax = c->rmax;
@@ -1204,7 +1219,7 @@ int bmx_ctx_surface(bmx_ctx *c, double test_gen, int64_t win_lo, int64_t win_hi,
     if (!c->has_model || !c->has_sites) return fail(BMX_E_STATE, "model and sites must be set before surface");
     HIP_TRY(hipSetDevice(c->device));
     SurfParams S;
-    S.genpos = c->d_genpos; S.row = c->d_row; S.N = c->N; S.Rt = c->d_Rt; S.NP = c->NP; S.npairs = c->npairs;
+    S.genpos = c->d_genpos; S.row = RowArray{c->d_row, c->d_row32}; S.N = c->N; S.Rt = c->d_Rt; S.NP = c->NP; S.npairs = c->npairs;
     S.nslices = c->nslices; S.A = c->d_A; S.nA = c->nA; S.tg = test_gen;
     S.lo = std::max<int64_t>(win_lo, 0); S.hi = std::min<int64_t>(win_hi, c->N - 1); S.zcut = c->zcut;
     double *dT = nullptr;

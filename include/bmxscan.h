@@ -33,7 +33,7 @@ enum {
     BMX_E_INVALID = -1,   /* bad argument (null pointer, size, unsorted positions, ...) */
     BMX_E_NODEVICE = -2,  /* no usable HIP device / device index out of range */
     BMX_E_HIP = -3,       /* a HIP runtime call failed; see bmx_last_error() */
-    BMX_E_LIMIT = -4,     /* a documented size limit was exceeded */
+    BMX_E_LIMIT = -4,     /* a documented size limit was exceeded (2^24 LUT rows, 2^31 sites, 2^31 grid points) */
     BMX_E_STATE = -5      /* call order violated (e.g. scan before model/sites were set) */
 };
 

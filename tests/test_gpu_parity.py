@@ -469,3 +469,46 @@ def test_fallback_paths_extreme_table_and_unsorted_tests():
     for a, b in zip(got, rev):
         assert np.array_equal(a, b[::-1])
     ctx.close()
+
+
+def test_more_than_65535_lut_rows():
+    """221 distinct sample sizes (300..520): 90 831 LUT rows, 4-byte row indices, R from global
+    memory.  A handful of test sites against the C oracle."""
+    eng = _engine()
+    L = c_oracle()
+    from ballermixplus_amd.hostmodel import Grids
+    rng = np.random.default_rng(21)
+    sizes = tuple(range(300, 521))
+    N = 3000
+    gen = np.cumsum(rng.geometric(0.02, N)) / 1e6
+    nn = rng.choice(np.array(sizes), N)
+    k = np.where(rng.random(N) < 0.5, nn, (rng.random(N) * (nn - 1)).astype(int) + 1)
+    cnt = {}
+    for a, b in zip(k.tolist(), nn.tolist()):
+        cnt[(a, b)] = cnt.get((a, b), 0) + 1
+    spect = {key: v / N for key, v in cnt.items()}
+    props = {}
+    for (a, b), v in spect.items():
+        props[b] = props.get(b, 0.0) + v
+    for n in sizes:
+        props.setdefault(n, 1e-9)
+    grid = Grids('0.3', None, True, False, None, '300,2000')
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays('B2', 1, sizes, spect, props, xs, ab)
+    assert model.rows > 65535
+    rows = model.rows_of(k, nn)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, rows)
+    _, R = ctx.fetch_lut()
+    Rfin = np.where(np.isfinite(R), R, 0.0)
+    idx = np.arange(1000, 1100)
+    lo, hi = np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64)
+    ctx.set_tests(gen[idx], lo, hi)
+    ctx.scan()
+    got = ctx.fetch()
+    ref = c_scan(L, Rfin, As, gen, rows, gen[idx], lo, hi)
+    for f in (1, 2, 3, 4):
+        assert np.array_equal(got[f], ref[f])
+    assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-12)
+    ctx.close()
