@@ -451,8 +451,12 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                 const bool inwin = inr && i >= lo_j && i <= hi_j;
                 const double z = A * fabs(g - tj);
                 const bool in = inwin && (z <= P.zcut) && (g != tj);
-                const bool fin = dir > 0 ? (!inr || i > hi_j || (i >= lo_j && g > tj && z > P.zcut))
-                                         : (!inr || i < lo_j || (i <= hi_j && g < tj && z > P.zcut));
+                // a lane is finished once nothing further along the walk can be in its window; an empty
+                // window (lo > hi: the padding test sites of a partial last group) is finished at once --
+                // without this the left walk of a partial group runs to index 0
+                const bool fin = lo_j > hi_j ||
+                                 (dir > 0 ? (!inr || i > hi_j || (i >= lo_j && g > tj && z > P.zcut))
+                                          : (!inr || i < lo_j || (i <= hi_j && g < tj && z > P.zcut)));
                 const unsigned long long m_in = __ballot(in);
                 if (m_in != 0ull) {
                     const double alpha = in ? exp_neg(z) : 0.0;
@@ -779,7 +783,7 @@ struct bmx_ctx {
     double *d_test_gen = nullptr;
     int64_t *d_win_lo = nullptr, *d_win_hi = nullptr, *d_center = nullptr, *d_center_hi = nullptr;
     bool tests_sorted = false;
-    bool tests_dense = false;   // neighbouring test sites are a few sites apart (median index gap <= 32)
+    int64_t test_gap = 1 << 30;  // median index gap between neighbouring test sites (sampled)
     double *d_part_T = nullptr;
     int32_t *d_part_lin = nullptr, *d_part_ns = nullptr;
     double *d_clr = nullptr;
@@ -1066,10 +1070,10 @@ int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64
         HIP_TRY(hipMemcpy(hc.data(), c->d_center, (size_t)ns * sizeof(int64_t), hipMemcpyDeviceToHost));
         std::vector<int64_t> gaps;
         for (int64_t t = 1; t < ns; t++) gaps.push_back(hc[(size_t)t] - hc[(size_t)t - 1]);
-        c->tests_dense = false;
+        c->test_gap = 1 << 30;
         if (!gaps.empty()) {
             std::nth_element(gaps.begin(), gaps.begin() + gaps.size() / 2, gaps.end());
-            c->tests_dense = gaps[gaps.size() / 2] <= 32;
+            c->test_gap = gaps[gaps.size() / 2];
         }
     }
     c->M = M;
@@ -1092,13 +1096,19 @@ int bmx_ctx_scan(bmx_ctx *c) {
     const bool fits = lds + (size_t)SCAN_THREADS_MAX * sizeof(ScratchEnt) <= (size_t)LDS_LIMIT_BYTES;
     // grouping pays when neighbouring test sites share most of their windows; a strided scan
     // (-s far larger than 1) is better served one test site per wave
-    const bool can_group = c->tests_sorted && c->tests_dense && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
+    // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3
+    // (windows/s x1000 for J = 16 / 8 / 4 / per-site): stride 1: 1558/1214/910/264, 5: 1100/1044/864,
+    // 8: 908/956/825, 16: 614/784/737, 32: 395/584/620, 192: -/-/296/253 -> J by the median gap between
+    // test sites; beyond ~200 sites the per-site kernel takes over.
+    const int64_t gap_max = getenv("BMX_DENSE_GAP") ? atoll(getenv("BMX_DENSE_GAP")) : 192;
+    const bool can_group = c->tests_sorted && c->test_gap <= gap_max && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
     int J = 0;
     // variants (A/B runs): 0 -> J=16, pairs near / quads far (default); 3 -> J=8, 4 -> J=4 (same form);
     //           8/9 -> J=16/8 pairs only; 5/6/7 -> J=16/8/4 readlane single-site loop; 1, 2 -> per-site kernel
     if (can_group) {
         const int v = c->variant;
         J = (v == 0 || v == 5 || v == 8) ? 16 : (v == 3 || v == 6 || v == 9) ? 8 : (v == 4 || v == 7) ? 4 : 0;
+        if (v == 0) J = c->test_gap <= 6 ? 16 : c->test_gap <= 20 ? 8 : 4;
     }
     P.sites_per_block = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : 4);
     if (J == 16 && P.sites_per_block < 64) P.sites_per_block = 64;

@@ -152,6 +152,7 @@ def _run():
     ap.add_argument('--config', type=int, default=3, choices=[3, 5],
                     help='3 (default): n=100, default 31x10x51 grid; 5: the dense-grid stress of BASELINE config 5 '
                          '(n=200, A=100..10000 step 100, --findBal --findPos grid) on one chromosome per GPU')
+    ap.add_argument('--step', type=int, default=1, help='test site = every step-th SNP (the reference\'s -s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-windows', type=int, default=48)
     args = ap.parse_args()
@@ -190,24 +191,26 @@ def _run():
     ctx.set_variant(args.variant)
     ctx.set_model(model, As)
     ctx.set_sites(gen, model.rows_of(k, nn))
-    ctx.set_tests(gen, np.zeros(N, np.int64), np.full(N, N - 1, np.int64))     # resident in HBM from here on
+    tidx = np.arange(0, N, args.step)
+    ctx.set_tests(gen[tidx], np.zeros(len(tidx), np.int64), np.full(len(tidx), N - 1, np.int64))   # resident in HBM from here on
 
     from ballermixplus_amd import _lib
     zcut = _lib.lib().bmx_alpha_cut()
-    wsum, wmax = window_work(gen, As, zcut, np.arange(N))
+    wsum, wmax = window_work(gen, As, zcut, tidx)
     evals_per_step = float(wsum.sum()) * len(xs) * len(ab)
-    bytes_per_step = float(wmax.sum()) * 10.0 + 24.0 * N      # W_max*10 B + 24 B per window
+    M = len(tidx)
+    bytes_per_step = float(wmax.sum()) * 10.0 + 24.0 * M      # W_max*10 B + 24 B per window
 
     def gather():
         if world.distributed:
             pc, pl, pn = ctx.result_ptrs()
             d = torch.device('cuda', dev)
-            clr = torch.as_tensor(distributed._DevArray(pc, N, '<f8'), device=d)
-            lin = torch.as_tensor(distributed._DevArray(pl, N, '<i4'), device=d)
-            ns = torch.as_tensor(distributed._DevArray(pn, N, '<i4'), device=d)
+            clr = torch.as_tensor(distributed._DevArray(pc, M, '<f8'), device=d)
+            lin = torch.as_tensor(distributed._DevArray(pl, M, '<i4'), device=d)
+            ns = torch.as_tensor(distributed._DevArray(pn, M, '<i4'), device=d)
             outs = []
             for t in (clr, lin, ns):
-                buf = torch.empty(N * world.size, dtype=t.dtype, device=d)
+                buf = torch.empty(M * world.size, dtype=t.dtype, device=d)
                 torch.distributed.all_gather_into_tensor(buf, t)
                 outs.append(buf)
             return outs
@@ -242,7 +245,7 @@ def _run():
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
-        windows = float(N) * world.size * args.steps
+        windows = float(M) * world.size * args.steps
         evals_s = evals_per_step / (k_ms * 1e-3)
         res = {
             'metric': 'CLR windows/sec (B2 scan, n=%d)' % n,
@@ -257,7 +260,7 @@ def _run():
                                     'per GPU' % (N, n)) if args.config == 3 else
                                    ('BASELINE config 5 grid on one chromosome per GPU: %d SNPs, n=%d, A=100..10000 step 100, '
                                     '--findBal --findPos (100x10x44), every SNP a test site' % (N, n)),
-                       'windows_per_step_per_gpu': N, 'grid_points': len(As) * len(xs) * len(ab),
+                       'windows_per_step_per_gpu': M, 'grid_points': len(As) * len(xs) * len(ab),
                        'parallelism': 'test-site sharding, dp%d, RCCL all_gather of 16-B records per step' % world.size,
                        'checksum_clr_rank0': checksum},
             'roofline': {

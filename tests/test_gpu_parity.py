@@ -512,3 +512,34 @@ def test_more_than_65535_lut_rows():
         assert np.array_equal(got[f], ref[f])
     assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-12)
     ctx.close()
+
+
+def test_partial_last_group_costs_nothing_extra():
+    """Performance guard: a test-site count that is not a multiple of the group size used to make
+    the padding lanes of the last group walk left to index 0 (seconds on a long chromosome).  The
+    kernel time for M = 16k + 5 must stay within 30 % of M = 16k, and strided scans must not fall
+    off a cliff."""
+    eng = _engine()
+    N, n = 400000, 100
+    phys, gen, k, nn, spect, props, grid = _synth_case(N, n)
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays('B2', int(k.min()), [n], spect, props, xs, ab)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, model.rows_of(k, nn))
+    times = {}
+    for M in (16384, 16384 + 5):
+        idx = np.arange(N - M, N)                       # the LAST sites of the chromosome: longest left walk
+        ctx.set_tests(gen[idx], np.zeros(M, np.int64), np.full(M, N - 1, np.int64))
+        ctx.scan(); ctx.sync()
+        ctx.scan(); ctx.sync()
+        times[M] = ctx.last_scan_ms()
+    assert times[16384 + 5] < 1.3 * times[16384] + 1.0, times
+    per_window = {}
+    for step in (1, 12, 40):
+        idx = np.arange(0, N, step)[:8000]
+        ctx.set_tests(gen[idx], np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64))
+        ctx.scan(); ctx.sync()
+        per_window[step] = ctx.last_scan_ms() / len(idx)
+    assert per_window[12] < 6 * per_window[1] and per_window[40] < 8 * per_window[1], per_window
+    ctx.close()
