@@ -285,16 +285,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_kernel(ScanParams P) {
                     const bool in = valid && (z <= P.zcut) && (g != tg);
                     const bool beyond = valid && (z > P.zcut);
                     const double alpha = in ? exp(-z) : 0.0;
-                    const int rowi = valid ? (int)P.row[i] : 0;
                     const unsigned long long m_in = __ballot(in);
                     ns += __popcll(m_in);
                     const int cnt = m_in ? 64 - __clzll((long long)m_in) : 0;
-                    for (int l = 0; l < cnt; ++l) {
-                        const double a_s = readlane_f64(alpha, l);
-                        const int r_s = __builtin_amdgcn_readlane(rowi, l);
-                        const double R = USE_LDS ? lds_R[r_s * WAVE + lane] : Rg[(size_t)r_s * P.NP];
-                        acc *= fma(a_s, R, 1.0);
-                        if (++since == P.renorm_every) {
+                    // lanes that are not in the window carry alpha = 0; give them the row of an in-window
+                    // lane so that 0*R is 0 and never 0*NaN (rows absent from the helper file hold NaN)
+                    int rowi = valid ? (int)P.row[i] : 0;
+                    if (cnt) rowi = in ? rowi : __builtin_amdgcn_readlane(rowi, __ffsll((long long)m_in) - 1);
+                    // four sites per iteration: the four R reads are in flight together, two
+                    // independent product chains
+                    for (int l = 0; l < cnt; l += 4) {
+                        double Rv[4], av[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int ll = min(l + u, WAVE - 1);
+                            av[u] = readlane_f64(alpha, ll);
+                            const int r_s = __builtin_amdgcn_readlane(rowi, ll);
+                            Rv[u] = USE_LDS ? lds_R[r_s * WAVE + lane] : Rg[(size_t)r_s * P.NP];
+                        }
+                        const double t01 = fma(av[0], Rv[0], 1.0) * fma(av[1], Rv[1], 1.0);
+                        const double t23 = fma(av[2], Rv[2], 1.0) * fma(av[3], Rv[3], 1.0);
+                        acc *= t01 * t23;
+                        since += 4;
+                        if (since + 4 > P.renorm_every) {
                             renorm(acc, E);
                             since = 0;
                         }
@@ -997,6 +1010,8 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     }
     if (!(fmax < 1e300)) return fail(BMX_E_INVALID, "selection table overflows (a neutral probability g is 0 or tiny)");
     c->span_hi = std::max(1, (int)std::ceil(std::log2(fmax)));
+    if (c->span_hi > 240)     // four factors are multiplied between exponent extractions
+        return fail(BMX_E_LIMIT, "selection table spans more than 2^240 (a neutral probability of ~1e-70?)");
     c->rmax = fmax - 1.0;
     // per-site kernel: worst case per factor is max(span_hi, 54 bits for 1 - alpha) -- see the kernel
     c->renorm_every = std::max(1, std::min(16, 1000 / std::max(c->span_hi, 54)));
@@ -1098,9 +1113,9 @@ int bmx_ctx_scan(bmx_ctx *c) {
     // (-s far larger than 1) is better served one test site per wave
     // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3
     // (windows/s x1000 for J = 16 / 8 / 4 / per-site): stride 1: 1558/1214/910/264, 5: 1100/1044/864,
-    // 8: 908/956/825, 16: 614/784/737, 32: 395/584/620, 192: -/-/296/253 -> J by the median gap between
-    // test sites; beyond ~200 sites the per-site kernel takes over.
-    const int64_t gap_max = getenv("BMX_DENSE_GAP") ? atoll(getenv("BMX_DENSE_GAP")) : 192;
+    // 8: 908/956/825, 16: 614/784/737, 32: 395/584/620, 128: -/-/374/340 -> J by the median gap between
+    // test sites; beyond ~130 sites the per-site kernel takes over.
+    const int64_t gap_max = getenv("BMX_DENSE_GAP") ? atoll(getenv("BMX_DENSE_GAP")) : 128;
     const bool can_group = c->tests_sorted && c->test_gap <= gap_max && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
     int J = 0;
     // variants (A/B runs): 0 -> J=16, pairs near / quads far (default); 3 -> J=8, 4 -> J=4 (same form);
