@@ -20,37 +20,60 @@ HEADER = 'physPos\tgenPos\tCLR\tx_hat\ts_hat\tA_hat\tnSites\n'
 
 class TestSites:
     """Test sites of one scan, in output order.  `na_rows` holds positions in the output where
-    the reference prints an 'NA' row instead of scanning (v1:534-536)."""
+    the reference prints an 'NA' row instead of scanning (v1:534-536).  The per-site lists
+    (phys, gen_label, test_gen, lo, hi) are materialised lazily when the sites came from one
+    vectorised add_many (a million-entry Python list costs more than the GPU scan)."""
+
+    _FIELDS = ('phys', 'gen_label', 'test_gen', 'lo', 'hi')
 
     def __init__(self):
-        self.phys, self.gen_label, self.test_gen, self.lo, self.hi = [], [], [], [], []
+        self._lists = {k: [] for k in self._FIELDS}
         self.na_rows = {}      # output position -> preformatted line
-        self.order = []        # output position of each scanned site
+        self._order = []       # output position of each scanned site (exposed as .order)
+        self.arrays = None     # (phys i64, gen f64, lo i64, hi i64) when built by one vectorised add_many
+        self._n = 0
+
+    def _materialise(self):
+        if self.arrays is not None and not self._lists['phys'] and self._n:
+            phys, gen, lo, hi = self.arrays
+            g = gen.tolist()
+            self._lists = {'phys': phys.tolist(), 'gen_label': g, 'test_gen': g, 'lo': lo.tolist(), 'hi': hi.tolist()}
+            self._order = list(range(self._n))
+
+    def __getattr__(self, name):
+        if name in TestSites._FIELDS:
+            self._materialise()
+            return self._lists[name]
+        if name == 'order':
+            self._materialise()
+            return self._order
+        raise AttributeError(name)
 
     def add(self, phys, gen_label, test_gen, lo, hi):
-        self.order.append(len(self.order) + len(self.na_rows))
-        self.phys.append(phys)
-        self.gen_label.append(gen_label)
-        self.test_gen.append(float(test_gen))
-        self.lo.append(int(lo))
-        self.hi.append(int(hi))
+        self._materialise()
+        self.arrays = None
+        self._order.append(self._n + len(self.na_rows))
+        self._n += 1
+        self._lists['phys'].append(phys)
+        self._lists['gen_label'].append(gen_label)
+        self._lists['test_gen'].append(float(test_gen))
+        self._lists['lo'].append(int(lo))
+        self._lists['hi'].append(int(hi))
 
     def add_na(self, line):
-        self.na_rows[len(self.order) + len(self.na_rows)] = line
+        self._materialise()
+        self.na_rows[self._n + len(self.na_rows)] = line
 
     def add_many(self, phys, gen_label, test_gen, lo, hi):
-        """Vectorised add() for modes whose test sites are a plain index stride."""
-        assert not self.na_rows
-        n0 = len(self.order)
-        self.order.extend(range(n0, n0 + len(phys)))
-        self.phys.extend(phys)
-        self.gen_label.extend(gen_label)
-        self.test_gen.extend(test_gen)
-        self.lo.extend(lo)
-        self.hi.extend(hi)
+        """Vectorised add() for modes whose test sites are a plain index stride (gen_label is
+        test_gen in those modes)."""
+        assert self._n == 0 and not self.na_rows
+        self.arrays = (np.asarray(phys, dtype=np.int64), np.asarray(test_gen, dtype=np.float64),
+                       np.asarray(lo, dtype=np.int64), np.asarray(hi, dtype=np.int64))
+        self._n = len(self.arrays[0])
 
     def __len__(self):
-        return len(self.order)
+        return self._n
 
 
 def sites_alpha(data, s):
@@ -58,8 +81,8 @@ def sites_alpha(data, s):
     ts = TestSites()
     N = data.numSites
     idx = np.arange(0, N, int(s))
-    g = data.genPos[idx].tolist()
-    ts.add_many(data.position[idx].tolist(), g, g, [0] * len(idx), [N - 1] * len(idx))
+    g = data.genPos[idx]
+    ts.add_many(data.position[idx], g, g, np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64))
     return ts
 
 
@@ -69,9 +92,8 @@ def sites_site_based(data, r, s):
     N = data.numSites
     if float(s) == int(s) and int(s) >= 1 and float(r) == int(r):      # the usual case, vectorised
         idx = np.arange(0, N, int(s))
-        g = data.genPos[idx].tolist()
-        ts.add_many(data.position[idx].tolist(), g, g, np.maximum(0, idx - int(r)).tolist(),
-                    np.minimum(N - 1, idx + int(r) + 1).tolist())
+        g = data.genPos[idx]
+        ts.add_many(data.position[idx], g, g, np.maximum(0, idx - int(r)), np.minimum(N - 1, idx + int(r) + 1))
         return ts
     i = 0
     while i < N:
@@ -101,8 +123,8 @@ def sites_fix_center(data, w, s):
             j = int(np.nonzero(end_i < start_i)[0][0])
             print(start[j], start_i[j], end[j], end_i[j])
             sys.exit(1)
-        g = data.genPos[idx].tolist()
-        ts.add_many(test.tolist(), g, g, start_i.tolist(), end_i.tolist())
+        g = data.genPos[idx]
+        ts.add_many(test, g, g, start_i, end_i)
         return ts
     i = 0
     start_i = 0
@@ -179,13 +201,17 @@ def write_rows(outfile, ts, results, sel):
     xs = [f'{v}' for v in sel.grid_x]
     abs_ = [f'{v}' for v in sel.grid_abeta]
     As = [f'{v}' for v in sel.grid_A]
-    if not ts.na_rows and len(ts) and all(isinstance(v, (int, np.integer)) for v in (ts.phys[0], ts.phys[-1])):
+    if not ts.na_rows and len(ts) and (ts.arrays is not None or
+                                       all(isinstance(v, (int, np.integer)) for v in (ts.phys[0], ts.phys[-1]))):
         try:          # native writer: same bytes, ~10x faster on million-row files
             from . import _lib
-            phys = np.asarray(ts.phys, dtype=np.int64)
+            if ts.arrays is not None:
+                phys, genl = ts.arrays[0], ts.arrays[1]
+            else:
+                phys, genl = np.asarray(ts.phys, dtype=np.int64), np.asarray(ts.gen_label, dtype=np.float64)
             with open(outfile, 'w') as scores:
                 scores.write(HEADER)
-            _lib.write_rows(outfile, phys, np.asarray(ts.gen_label, dtype=np.float64), clr, ix, ia, iA, ns, xs, abs_, As)
+            _lib.write_rows(outfile, phys, genl, clr, ix, ia, iA, ns, xs, abs_, As)
             return
         except (ImportError, OSError, AttributeError):
             pass
@@ -237,7 +263,10 @@ class Scan:
         NormalizedBetaBinom.bind(NeutralSFS)
         run = runner or engine.scan_batch
         if len(ts):
-            results = run(NormalizedBetaBinom, ts.test_gen, ts.lo, ts.hi)
+            if ts.arrays is not None:
+                results = run(NormalizedBetaBinom, ts.arrays[1], ts.arrays[2], ts.arrays[3])
+            else:
+                results = run(NormalizedBetaBinom, ts.test_gen, ts.lo, ts.hi)
         else:
             results = (np.zeros(0), np.zeros(0, int), np.zeros(0, int), np.zeros(0, int), np.zeros(0, int))
         self.test_sites = ts

@@ -235,7 +235,7 @@ def cmd_synth(which):
     ref = load_ref()
     outdir = os.path.join(HERE, 'synth')
     os.makedirs(outdir, exist_ok=True)
-    cfgs = {'20k': (20000, 100, 1, 200), '1M': (1000000, 100, 1, 100000),
+    cfgs = {'20k': (20000, 100, 1, 200), '1M': (1000000, 100, 1, 100000), '1M_dense': (1000000, 100, 1, 4000),
             '20k_n200_bal': (20000, 200, 2, 400)}
     for key in which:
         N, n, chrom, step = cfgs[key]
@@ -263,7 +263,7 @@ def cmd_synth(which):
             r = ref.calcBaller(allidx, data.genPos[i], data, neut, nb, grid)
             rows.append(f'{data.position[i]}\t{data.genPos[i]}\t{r[0]}\t{r[1]}\t{r[2]}\t{r[3]}\t{r[4]}')
             print(key, i, rows[-1], '%.1fs' % (time.time() - t0), flush=True)
-        with open(os.path.join(outdir, 'synth_%s_step%d.tsv' % (key, step)), 'w') as f:
+        with open(os.path.join(outdir, 'synth_%s_step%d.tsv' % (key.replace('_dense', ''), step)), 'w') as f:
             f.write('physPos\tgenPos\tCLR\tx_hat\ts_hat\tA_hat\tnSites\n')
             f.write('\n'.join(rows) + '\n')
 
