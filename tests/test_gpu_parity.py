@@ -549,3 +549,39 @@ def test_partial_last_group_costs_nothing_extra():
         per_window[step] = ctx.last_scan_ms() / len(idx)
     assert per_window[12] < 6 * per_window[1] and per_window[40] < 8 * per_window[1], per_window
     ctx.close()
+
+
+def test_grouped_kernel_at_config3_scale_against_the_reference():
+    """The shipped (grouped, J = 16) kernel vs the REFERENCE at full config-3 size: each of the 250
+    sites the reference scanned (tests/golden/synth/synth_1M_step4000.tsv, reference run with -s 4000)
+    is embedded in a run of 16 consecutive test sites, so that it goes through a full group with bulk
+    zones, pairs/quads and ragged ends -- not through the per-site kernel the strided scan uses."""
+    path = os.path.join(GOLD, 'synth', 'synth_1M_step4000.tsv')
+    if not os.path.exists(path):
+        pytest.skip('fixture not generated')
+    eng = _engine()
+    N, n = 1000000, 100
+    phys, gen, k, nn, spect, props, grid = _synth_case(N, n)
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays('B2', int(k.min()), [n], spect, props, xs, ab)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, model.rows_of(k, nn))
+    ref_idx = np.arange(0, N, 4000)
+    rows = read_tsv(path)
+    assert len(rows) == len(ref_idx)
+    off = np.arange(-5, 11)                                 # the reference site is the 6th of its group
+    idx = np.clip(ref_idx[:, None] + off[None, :], 0, N - 1).reshape(-1)
+    idx = np.unique(idx)
+    ctx.set_tests(gen[idx], np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64))
+    ctx.scan()
+    clr, ix, ia, iA, ns = ctx.fetch()
+    where = np.searchsorted(idx, ref_idx)
+    for j, r in zip(where, rows):
+        assert int(r[0]) == phys[idx[j]]
+        if r[3:6] == ['0.0', '0.0', '0.0']:
+            assert iA[j] < 0
+            continue
+        assert (repr(xs[ix[j]]), repr(ab[ia[j]]), repr(As[iA[j]]), str(ns[j])) == (r[3], r[4], r[5], r[6]), (j, r)
+        assert abs(clr[j] - float(r[2])) <= max(1e-9, 1e-6 * abs(float(r[2]))), (j, r, clr[j])
+    ctx.close()
