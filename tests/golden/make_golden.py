@@ -235,7 +235,7 @@ def cmd_synth(which):
     ref = load_ref()
     outdir = os.path.join(HERE, 'synth')
     os.makedirs(outdir, exist_ok=True)
-    cfgs = {'20k': (20000, 100, 1, 200), '1M': (1000000, 100, 1, 100000), '1M_dense': (1000000, 100, 1, 4000),
+    cfgs = {'20k': (20000, 100, 1, 200), '1M': (1000000, 100, 1, 100000), '1M_dense': (1000000, 100, 1, 4000), '1M_n200_bal': (1000000, 200, 2, 40000),
             '20k_n200_bal': (20000, 200, 2, 400)}
     for key in which:
         N, n, chrom, step = cfgs[key]

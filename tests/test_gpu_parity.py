@@ -99,7 +99,8 @@ def _synth_case(N, n, chrom=1, bal=False, listA=None):
 
 
 @pytest.mark.parametrize('key,N,n,step,bal', [('20k', 20000, 100, 200, False), ('20k_n200_bal', 20000, 200, 400, True),
-                                              ('1M', 1000000, 100, 100000, False), ('1M', 1000000, 100, 4000, False)])
+                                              ('1M', 1000000, 100, 100000, False), ('1M', 1000000, 100, 4000, False),
+                                              ('1M_n200_bal', 1000000, 200, 40000, True)])
 def test_synthetic_strided_windows_match_reference(key, N, n, step, bal):
     """BASELINE configs 3/5 in miniature + config 3 at full size on the windows the reference
     could afford (tests/golden/synth, produced by running the reference with -s)."""
