@@ -161,12 +161,18 @@ def _run():
     from ballermixplus_amd import distributed, engine, synth
     from ballermixplus_amd.hostmodel import Grids
 
-    world = distributed.World.from_env()
+    # BMX_DIST_BACKEND=gloo + BMX_SINGLE_DEVICE=1: several ranks sharing ONE GPU with a CPU gather -- only to
+    # rehearse the multi-rank control flow (barriers, max-over-ranks, rank-0 output) on a 1-GPU box
+    world = distributed.World.from_env(backend=os.environ.get('BMX_DIST_BACKEND'))
     if world.size != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world.size, args.gpus))
     rank, dev = world.rank, world.local_rank
+    if os.environ.get('BMX_SINGLE_DEVICE') == '1':
+        dev = 0
     torch.cuda.set_device(dev)
+    on_gpu = world.backend != 'gloo'
+    cdev = torch.device('cuda', dev) if on_gpu else torch.device('cpu')
 
     N, n = args.snps, args.n
     if args.config == 5:
@@ -203,14 +209,17 @@ def _run():
 
     def gather():
         if world.distributed:
-            pc, pl, pn = ctx.result_ptrs()
-            d = torch.device('cuda', dev)
-            clr = torch.as_tensor(distributed._DevArray(pc, M, '<f8'), device=d)
-            lin = torch.as_tensor(distributed._DevArray(pl, M, '<i4'), device=d)
-            ns = torch.as_tensor(distributed._DevArray(pn, M, '<i4'), device=d)
+            if on_gpu:      # zero-copy views of the library's device buffers -> RCCL
+                pc, pl, pn = ctx.result_ptrs()
+                clr = torch.as_tensor(distributed._DevArray(pc, M, '<f8'), device=cdev)
+                lin = torch.as_tensor(distributed._DevArray(pl, M, '<i4'), device=cdev)
+                ns = torch.as_tensor(distributed._DevArray(pn, M, '<i4'), device=cdev)
+            else:           # rehearsal mode: through the host
+                c_, ix_, ia_, iA_, n_ = ctx.fetch()
+                clr, lin, ns = torch.from_numpy(c_), torch.from_numpy(iA_.copy()), torch.from_numpy(n_)
             outs = []
             for t in (clr, lin, ns):
-                buf = torch.empty(M * world.size, dtype=t.dtype, device=d)
+                buf = torch.empty(M * world.size, dtype=t.dtype, device=cdev)
                 torch.distributed.all_gather_into_tensor(buf, t)
                 outs.append(buf)
             return outs
@@ -236,7 +245,7 @@ def _run():
     barrier()
     dt = time.perf_counter() - t0
     if world.distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device('cuda', dev))
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
