@@ -1,8 +1,14 @@
 // bmxscan.hip -- libbmxscan.so: gfx950 kernels + C ABI (include/bmxscan.h).
 //
 // Hot path being replaced (reference BalLeRMix+_v1.py, "v1:LINE"):
-//   K1  bb_lut_kernel   <- NormalizedBetaBinom.__init__/get_raw_probs/get_*_normBase  v1:319-433
-//   K2  clr_scan_kernel <- calcBaller                                                v1:436-507
+//   K1  bb_lut_kernel            <- NormalizedBetaBinom.__init__/get_raw_probs/get_*_normBase  v1:319-433
+//   K2  clr_scan_grouped_kernel  <- calcBaller, J test sites per wave (what ships)           v1:436-507
+//       clr_scan_kernel          <- calcBaller, one test site per wave (sparse test sets, fallback)
+//       locate_kernel / finalize_kernel: test-site positions, per-slice argmax merge + nSites
+//       surface_kernel           <- the full T[A,x,alpha] surface of one site (v1:449-450 wish)
+//
+// Environment knobs (diagnostics / A-B runs only): BMX_TRACE, BMX_LDS_PAD, BMX_DENSE_GAP; the scan
+// variant is chosen with bmx_ctx_set_variant().
 //
 // K2 formulation.  For a test site t and linkage value A the reference sums, over the sites
 // i of the window with alpha_i = exp(-A*|g_i - t|) >= 1e-8 and g_i != t (v1:454-457),
