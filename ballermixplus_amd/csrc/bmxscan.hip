@@ -202,6 +202,8 @@ struct ScanParams {
     int renorm_every;  // per-site kernel: sites between exponent extractions
     int span_hi;       // grouped kernel: bits by which one factor 1+alpha*R can exceed 1 (>= 1)
     double rmax;       // max(0, largest finite R of the table)
+    double far_theta;  // grouped kernel, FARSUM: sites with E <= far_theta = far_eps / max|R| go through power sums
+    float far_bits;    // far_eps * log2(e): exponent-budget bits per far site
     int sites_per_block;
     double *part_T;    // [nslices][M]
     int32_t *part_lin;
@@ -390,7 +392,8 @@ template <int J, bool USE_LDS, int MODE_>
 __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(ScanParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then scratch
     constexpr int SP = WAVE / J;                                    // sites per generic pass
-    constexpr bool QUAD = (MODE_ == 2);                             // MODE_ 2 = MODE 1 + quads in far passes
+    constexpr bool QUAD = (MODE_ >= 2);                             // MODE_ 2 = MODE 1 + quads in far passes
+    constexpr bool FARSUM = (MODE_ == 3);                           // MODE_ 3 = MODE 2 + power sums in the far field
     constexpr int MODE = MODE_ ? 1 : 0;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x >> 6;
@@ -522,6 +525,9 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                 int i = base + dir * lane;
                 double g_nx = P.genpos[min(max(i, 0), N - 1)];
                 int r_nx = (int)P.row[min(max(i, 0), N - 1)];
+                // far field (FARSUM): power sums p_k = sum v^k of the sites whose E <= far_theta, per lane
+                double p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
+                int nfar_tot = 0;
                 while (true) {
                     const bool ok = dir > 0 ? (i <= hi_min) : (i >= lo_max);
                     const double g = g_nx;
@@ -545,9 +551,47 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                         const int lowbits = 1024 - ((__double2hiint(om) >> 20) & 0x7ff);
                         const int hibits = ((__double2hiint(op) >> 20) & 0x7ff) - 1022;
                         const int span8 = 8 * min(max(hibits, lowbits), 125);
+                        int cnt_blk = cnt;                              // sites left to the block loops
                         if (MODE == 1) {
                             scr[lane] = ScratchEnt{Ev, rowoff, 0};
                             __builtin_amdgcn_wave_barrier();
+                            if (FARSUM) {
+                                // E decreases along the walk, so the far sites are the tail [cnt_near, cnt)
+                                const bool farl = bulk && Ev <= P.far_theta && nfar_tot < 65536;   // see the bound below
+                                const int nfar = __popcll(__ballot(farl));
+                                if (nfar) {
+                                    int l = cnt - nfar;
+                                    for (; l + 4 <= cnt; l += 4) {
+                                        double v[4];
+#pragma unroll
+                                        for (int u = 0; u < 4; ++u) {
+                                            const ScratchEnt en = scr[l + u];
+                                            v[u] = en.e * loadR(en.ro);
+                                        }
+#pragma unroll
+                                        for (int u = 0; u < 4; ++u) {
+                                            const double v2 = v[u] * v[u];
+                                            p1 += v[u];
+                                            p2 += v2;
+                                            p3 = fma(v2, v[u], p3);
+                                            p4 = fma(v2, v2, p4);
+                                        }
+                                    }
+                                    for (; l < cnt; ++l) {
+                                        const ScratchEnt en = scr[l];
+                                        const double v = en.e * loadR(en.ro), v2 = v * v;
+                                        p1 += v;
+                                        p2 += v2;
+                                        p3 = fma(v2, v, p3);
+                                        p4 = fma(v2, v2, p4);
+                                    }
+                                    nfar_tot += nfar;
+                                    __builtin_amdgcn_wave_barrier();
+                                    if (farl) scr[lane].e = 0.0;       // the block loops below see factor 1
+                                    __builtin_amdgcn_wave_barrier();
+                                    cnt_blk = cnt - nfar;
+                                }
+                            }
                             constexpr int BS = J >= 16 ? 4 : 8;        // sites per unrolled block
                             // Far passes (every alpha <= 1/2: factors >= 1/2, the expanded product is well
                             // conditioned) can take FOUR sites per step:
@@ -555,7 +599,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             // e_k = elementary symmetric polynomials of v_1..v_4 shared by all J test sites:
                             // 4 FMA + 1 MUL per test site per four sites.
                             if (QUAD && lowbits <= 2) {
-                                for (int l0 = 0; l0 < cnt; l0 += 4) {
+                                for (int l0 = 0; l0 < cnt_blk; l0 += 4) {
                                     spend(span8 / 2);
                                     double v[4];
 #pragma unroll
@@ -579,7 +623,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                     }
                                 }
                             } else
-                            for (int l0 = 0; l0 < cnt; l0 += BS) {
+                            for (int l0 = 0; l0 < cnt_blk; l0 += BS) {
                                 spend(span8 * BS / 8);
                                 double v[BS];
 #pragma unroll
@@ -611,6 +655,20 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     base += dir * cnt;
                     if (cnt < WAVE) break;
                     i = inx;
+                }
+                if (FARSUM && nfar_tot) {
+                    // sum_i log1p(F v_i) = F p1 - F^2 p2/2 + F^3 p3/3 - F^4 p4/4 + ...  with
+                    // |F v_i| <= E_i max|R| <= far_eps.  Dropped: < far_eps^5/5 for the nearest far site and
+                    // e^-5 of that per further unit of A*d, i.e. ~far_eps^5/25 times the number of sites per
+                    // unit of A*d (135 for config 3 at A = 100): 2e-12 if every R were max|R|; measured
+                    // 1e-14.  |sum| <= nfar_tot*far_eps < 656, inside exp's range and the exponent budget.
+                    spend(2 + (int)((float)nfar_tot * P.far_bits));
+                    const double h2 = 0.5 * p2, h3 = p3 * 0.3333333333333333, h4 = 0.25 * p4;
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        const double t = F[j] * (p1 - F[j] * (h2 - F[j] * (h3 - F[j] * h4)));
+                        acc[j] *= exp_neg(-t);
+                    }
                 }
                 return base;
             };
@@ -1111,6 +1169,12 @@ int bmx_ctx_scan(bmx_ctx *c) {
     P.rows = c->rows; P.NP = c->NP; P.npairs = c->npairs; P.nslices = c->nslices;
     P.A = c->d_A; P.nA = c->nA; P.test_gen = c->d_test_gen; P.win_lo = c->d_win_lo; P.win_hi = c->d_win_hi;
     P.center = c->d_center; P.center_hi = c->d_center_hi; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi; P.rmax = c->rmax;
+    {
+        double eps = getenv("BMX_FAR_EPS") ? atof(getenv("BMX_FAR_EPS")) : 5e-3;   // accuracy experiments
+        eps = std::min(std::max(eps, 0.0), 1e-2);
+        P.far_theta = eps / std::max(c->rmax, 1.0);   // |R| <= max(rmax, 1): R >= -1
+        P.far_bits = (float)(eps * 1.4427);
+    }
     P.part_T = c->d_part_T; P.part_lin = c->d_part_lin; P.part_ns = c->d_part_ns;
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
     if (const char *pad = getenv("BMX_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
@@ -1124,11 +1188,12 @@ int bmx_ctx_scan(bmx_ctx *c) {
     const int64_t gap_max = getenv("BMX_DENSE_GAP") ? atoll(getenv("BMX_DENSE_GAP")) : 128;
     const bool can_group = c->tests_sorted && c->test_gap <= gap_max && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
     int J = 0;
-    // variants (A/B runs): 0 -> J=16, pairs near / quads far (default); 3 -> J=8, 4 -> J=4 (same form);
+    // variants (A/B runs): 0 -> J by test-site gap, pairs near / quads mid / power sums far (default);
+    //           3 -> J=8, 4 -> J=4 (same form); 10/11 -> J=16/8 without the power sums (exact products);
     //           8/9 -> J=16/8 pairs only; 5/6/7 -> J=16/8/4 readlane single-site loop; 1, 2 -> per-site kernel
     if (can_group) {
         const int v = c->variant;
-        J = (v == 0 || v == 5 || v == 8) ? 16 : (v == 3 || v == 6 || v == 9) ? 8 : (v == 4 || v == 7) ? 4 : 0;
+        J = (v == 0 || v == 5 || v == 8 || v == 10) ? 16 : (v == 3 || v == 6 || v == 9 || v == 11) ? 8 : (v == 4 || v == 7) ? 4 : 0;
         if (v == 0) J = c->test_gap <= 6 ? 16 : c->test_gap <= 20 ? 8 : 4;
     }
     P.sites_per_block = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : 4);
@@ -1141,11 +1206,11 @@ int bmx_ctx_scan(bmx_ctx *c) {
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     const void *fn = nullptr;
 #define PICK(K) (use_lds ? (const void *)K<true> : (const void *)K<false>)
-    // inner-loop form: 0 readlane / one site per step; 1 LDS broadcast + pairs; 2 (default) = 1 + four
-    // sites per step in far passes
-    const int mode = (c->variant >= 5 && c->variant <= 7) ? 0 : (c->variant >= 8 && c->variant <= 9) ? 1 : 2;
+    // inner-loop form: 0 readlane / one site per step; 1 LDS broadcast + pairs; 2 = 1 + four sites per
+    // step where every alpha <= 1/2; 3 (default) = 2 + power sums where alpha*max|R| <= far_eps
+    const int mode = (c->variant >= 5 && c->variant <= 7) ? 0 : (c->variant >= 8 && c->variant <= 9) ? 1 : (c->variant >= 10 && c->variant <= 11) ? 2 : 3;
 #define GP2(JJ, MM) (use_lds ? (const void *)clr_scan_grouped_kernel<JJ, true, MM> : (const void *)clr_scan_grouped_kernel<JJ, false, MM>)
-#define GPICK(JJ) (mode == 2 ? GP2(JJ, 2) : mode == 1 ? GP2(JJ, 1) : GP2(JJ, 0))
+#define GPICK(JJ) (mode == 3 ? GP2(JJ, 3) : mode == 2 ? GP2(JJ, 2) : mode == 1 ? GP2(JJ, 1) : GP2(JJ, 0))
     if (J == 8) fn = GPICK(8);
     else if (J == 16) fn = GPICK(16);
     else if (J == 4) fn = GPICK(4);

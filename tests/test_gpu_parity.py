@@ -316,6 +316,10 @@ def test_multiple_sample_sizes_and_large_tables(sizes, label):
     ctx.close()
 
 
+# kernel variants exercised by the randomised scenarios (bmx_ctx_set_variant); overridable for fuzz runs
+RANDOMISED_VARIANTS = tuple(int(v) for v in os.environ.get('BMX_TEST_VARIANTS', '0,2,3,8,10').split(','))
+
+
 @pytest.mark.parametrize('seed', list(range(15)))
 def test_randomised_scenarios_against_oracle(seed):
     """Seeded random inputs through both kernels (grouped and per-site) vs the C oracle: random
@@ -385,7 +389,7 @@ def test_randomised_scenarios_against_oracle(seed):
         if mode == 3:
             hi = np.maximum(hi - rng.integers(0, 2 * r, M), 0)
     ref = c_scan(L, Rfin, As, gen, rows, tg, lo, hi)
-    for variant in (0, 2, 3, 8):
+    for variant in RANDOMISED_VARIANTS:
         ctx.set_variant(variant)
         ctx.set_tests(tg, lo, hi)
         ctx.scan()
