@@ -202,7 +202,8 @@ struct ScanParams {
     int renorm_every;  // per-site kernel: sites between exponent extractions
     int span_hi;       // grouped kernel: bits by which one factor 1+alpha*R can exceed 1 (>= 1)
     double rmax;       // max(0, largest finite R of the table)
-    double far_theta;  // grouped kernel, FARSUM: sites with E <= far_theta = far_eps / max|R| go through power sums
+    double far_eps;    // grouped kernel, FARSUM: sites with E * rowmax[row] <= far_eps go through power sums
+    const double *rowmax;  // [nslices][rows]: max |R| of the row over the slice's 64 pairs (+inf for absent rows)
     float far_bits;    // far_eps * log2(e): exponent-budget bits per far site
     int sites_per_block;
     double *part_T;    // [nslices][M]
@@ -407,14 +408,18 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
         const int total = P.rows * WAVE;
         for (int idx = threadIdx.x; idx < total; idx += blockDim.x)
             lds_R[idx] = P.Rt[(size_t)(idx >> 6) * P.NP + slice * WAVE + (idx & 63)];
+        for (int idx = threadIdx.x; idx < P.rows; idx += blockDim.x)
+            lds_R[total + idx] = P.rowmax[(size_t)slice * P.rows + idx];
         __syncthreads();
     }
     const double *Rg = P.Rt + slice * WAVE + lane;
     auto loadR = [&](int rowoff) -> double {                       // rowoff = row * 64
         return USE_LDS ? lds_R[rowoff + lane] : Rg[(size_t)(rowoff >> 6) * P.NP];
     };
-    // wave-private scratch behind the R slice: 64 x 16 B
-    ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_R + (USE_LDS ? P.rows * WAVE : 0)) + wave * WAVE;
+    // per-row max |R| of this slice (behind the R slice), then the wave-private scratch: 64 x 16 B
+    const int rows_pad = (P.rows + 1) & ~1;
+    const double *rowmax = USE_LDS ? lds_R + P.rows * WAVE : P.rowmax + (size_t)slice * P.rows;
+    ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_R + (USE_LDS ? P.rows * WAVE + rows_pad : 0)) + wave * WAVE;
     double *scr_d = reinterpret_cast<double *>(scr);
 
     const int64_t ngroups = (P.M + J - 1) / J;
@@ -553,44 +558,55 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                         const int span8 = 8 * min(max(hibits, lowbits), 125);
                         int cnt_blk = cnt;                              // sites left to the block loops
                         if (MODE == 1) {
-                            scr[lane] = ScratchEnt{Ev, rowoff, 0};
-                            __builtin_amdgcn_wave_barrier();
+                            // FARSUM: a site is far when alpha*|R| <= far_eps for every pair of the slice and every
+                            // test site (alpha = E F <= E).  Far sites go through the power sums and are listed
+                            // behind the near ones in the scratch; the block loops only see the near list.
+                            bool farl = false;
+                            int nfar = 0, pos = lane;
                             if (FARSUM) {
-                                // E decreases along the walk, so the far sites are the tail [cnt_near, cnt)
-                                const bool farl = bulk && Ev <= P.far_theta && nfar_tot < 65536;   // see the bound below
-                                const int nfar = __popcll(__ballot(farl));
+                                farl = bulk && Ev * rowmax[rraw] <= P.far_eps && nfar_tot < 65536;   // see the bound below
+                                const unsigned long long mf = __ballot(farl);
+                                nfar = __popcll(mf);
                                 if (nfar) {
-                                    int l = cnt - nfar;
-                                    for (; l + 4 <= cnt; l += 4) {
-                                        double v[4];
+                                    const unsigned long long mn = mb & ~mf;
+                                    const int rf = __builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0u));
+                                    const int rn = __builtin_amdgcn_mbcnt_hi((unsigned)(mn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mn, 0u));
+                                    pos = farl ? cnt - nfar + rf : (bulk ? rn : lane);   // lanes past the bulk prefix keep their slot
+                                }
+                            }
+                            scr[pos] = ScratchEnt{Ev, rowoff, 0};
+                            __builtin_amdgcn_wave_barrier();
+                            if (FARSUM && nfar) {
+                                int l = cnt - nfar;
+                                for (; l + 4 <= cnt; l += 4) {
+                                    double v[4];
 #pragma unroll
-                                        for (int u = 0; u < 4; ++u) {
-                                            const ScratchEnt en = scr[l + u];
-                                            v[u] = en.e * loadR(en.ro);
-                                        }
-#pragma unroll
-                                        for (int u = 0; u < 4; ++u) {
-                                            const double v2 = v[u] * v[u];
-                                            p1 += v[u];
-                                            p2 += v2;
-                                            p3 = fma(v2, v[u], p3);
-                                            p4 = fma(v2, v2, p4);
-                                        }
+                                    for (int u = 0; u < 4; ++u) {
+                                        const ScratchEnt en = scr[l + u];
+                                        v[u] = en.e * loadR(en.ro);
                                     }
-                                    for (; l < cnt; ++l) {
-                                        const ScratchEnt en = scr[l];
-                                        const double v = en.e * loadR(en.ro), v2 = v * v;
-                                        p1 += v;
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        const double v2 = v[u] * v[u];
+                                        p1 += v[u];
                                         p2 += v2;
-                                        p3 = fma(v2, v, p3);
+                                        p3 = fma(v2, v[u], p3);
                                         p4 = fma(v2, v2, p4);
                                     }
-                                    nfar_tot += nfar;
-                                    __builtin_amdgcn_wave_barrier();
-                                    if (farl) scr[lane].e = 0.0;       // the block loops below see factor 1
-                                    __builtin_amdgcn_wave_barrier();
-                                    cnt_blk = cnt - nfar;
                                 }
+                                for (; l < cnt; ++l) {
+                                    const ScratchEnt en = scr[l];
+                                    const double v = en.e * loadR(en.ro), v2 = v * v;
+                                    p1 += v;
+                                    p2 += v2;
+                                    p3 = fma(v2, v, p3);
+                                    p4 = fma(v2, v2, p4);
+                                }
+                                nfar_tot += nfar;
+                                __builtin_amdgcn_wave_barrier();
+                                if (farl) scr[pos].e = 0.0;            // the block loops below see factor 1
+                                __builtin_amdgcn_wave_barrier();
+                                cnt_blk = cnt - nfar;
                             }
                             constexpr int BS = J >= 16 ? 4 : 8;        // sites per unrolled block
                             // Far passes (every alpha <= 1/2: factors >= 1/2, the expanded product is well
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                 }
                 if (FARSUM && nfar_tot) {
                     // sum_i log1p(F v_i) = F p1 - F^2 p2/2 + F^3 p3/3 - F^4 p4/4 + ...  with
-                    // |F v_i| <= E_i max|R| <= far_eps.  Dropped: < far_eps^5/5 for the nearest far site and
+                    // |F v_i| <= E_i rowmax <= far_eps.  Dropped: < far_eps^5/5 for the nearest far site and
                     // e^-5 of that per further unit of A*d, i.e. ~far_eps^5/25 times the number of sites per
                     // unit of A*d (135 for config 3 at A = 100): 2e-12 if every R were max|R|; measured
                     // 1e-14.  |sum| <= nfar_tot*far_eps < 656, inside exp's range and the exponent budget.
@@ -843,7 +859,7 @@ struct bmx_ctx {
     double rmax = 0.0;
     int32_t *d_sizes = nullptr, *d_row_off = nullptr;
     double *d_g = nullptr, *d_prop = nullptr, *d_x = nullptr, *d_abeta = nullptr, *d_A = nullptr;
-    double *d_psel = nullptr, *d_R = nullptr, *d_Rt = nullptr;
+    double *d_psel = nullptr, *d_R = nullptr, *d_Rt = nullptr, *d_rowmax = nullptr;
     uint64_t *d_patch_x = nullptr;
     double *d_patch_y = nullptr;
     int n_patch = 0;
@@ -872,7 +888,7 @@ namespace {
 
 void free_model(bmx_ctx *c) {
     dfree(c->d_sizes); dfree(c->d_row_off); dfree(c->d_g); dfree(c->d_prop); dfree(c->d_x);
-    dfree(c->d_abeta); dfree(c->d_A); dfree(c->d_psel); dfree(c->d_R); dfree(c->d_Rt);
+    dfree(c->d_abeta); dfree(c->d_A); dfree(c->d_psel); dfree(c->d_R); dfree(c->d_Rt); dfree(c->d_rowmax);
     dfree(c->d_patch_x); dfree(c->d_patch_y);
     c->has_model = false;
 }
@@ -1077,6 +1093,16 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     if (c->span_hi > 240)     // four factors are multiplied between exponent extractions
         return fail(BMX_E_LIMIT, "selection table spans more than 2^240 (a neutral probability of ~1e-70?)");
     c->rmax = fmax - 1.0;
+    {   // per slice and row: the largest |R| over the slice's pairs (grouped kernel's far-field test)
+        std::vector<double> rm((size_t)c->nslices * c->rows, 0.0);
+        for (int p = 0; p < c->npairs; p++)
+            for (int r = 0; r < c->rows; r++) {
+                const double v = std::fabs(hR[(size_t)p * c->rows + r]);
+                double &m = rm[(size_t)(p / WAVE) * c->rows + r];
+                m = (v != v) ? INFINITY : std::max(m, v);
+            }
+        if ((rc = upload(c->d_rowmax, rm.data(), rm.size(), c->stream))) return rc;
+    }
     // per-site kernel: worst case per factor is max(span_hi, 54 bits for 1 - alpha) -- see the kernel
     c->renorm_every = std::max(1, std::min(16, 1000 / std::max(c->span_hi, 54)));
     c->has_model = true;
@@ -1170,15 +1196,16 @@ int bmx_ctx_scan(bmx_ctx *c) {
     P.A = c->d_A; P.nA = c->nA; P.test_gen = c->d_test_gen; P.win_lo = c->d_win_lo; P.win_hi = c->d_win_hi;
     P.center = c->d_center; P.center_hi = c->d_center_hi; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi; P.rmax = c->rmax;
     {
-        double eps = getenv("BMX_FAR_EPS") ? atof(getenv("BMX_FAR_EPS")) : 5e-3;   // accuracy experiments
+        double eps = getenv("BMX_FAR_EPS") ? atof(getenv("BMX_FAR_EPS")) : 2e-3;   // accuracy experiments
         eps = std::min(std::max(eps, 0.0), 1e-2);
-        P.far_theta = eps / std::max(c->rmax, 1.0);   // |R| <= max(rmax, 1): R >= -1
+        P.far_eps = eps;
+        P.rowmax = c->d_rowmax;
         P.far_bits = (float)(eps * 1.4427);
     }
     P.part_T = c->d_part_T; P.part_lin = c->d_part_lin; P.part_ns = c->d_part_ns;
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
     if (const char *pad = getenv("BMX_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
-    const bool fits = lds + (size_t)SCAN_THREADS_MAX * sizeof(ScratchEnt) <= (size_t)LDS_LIMIT_BYTES;
+    const bool fits = lds + (size_t)(c->rows + 2) * sizeof(double) + (size_t)SCAN_THREADS_MAX * sizeof(ScratchEnt) <= (size_t)LDS_LIMIT_BYTES;
     // grouping pays when neighbouring test sites share most of their windows; a strided scan
     // (-s far larger than 1) is better served one test site per wave
     // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3
@@ -1221,10 +1248,11 @@ int bmx_ctx_scan(bmx_ctx *c) {
     // One wave per SIMD issues FP64 at half rate (measured), so a workgroup whose LDS footprint
     // allows only one resident workgroup per CU gets 8 waves instead of 4.
     int threads = SCAN_THREADS;
-    size_t lds_bytes = (use_lds ? lds : 0) + (J ? (size_t)threads * sizeof(ScratchEnt) : 0);
+    const size_t lds_rm = (size_t)((c->rows + 1) & ~1) * sizeof(double);    // grouped kernels: per-row max |R| behind the slice
+    size_t lds_bytes = (use_lds ? lds + (J ? lds_rm : 0) : 0) + (J ? (size_t)threads * sizeof(ScratchEnt) : 0);
     if (J && 2 * lds_bytes > (size_t)LDS_LIMIT_BYTES) {
         threads = SCAN_THREADS_MAX;
-        lds_bytes = (use_lds ? lds : 0) + (size_t)threads * sizeof(ScratchEnt);
+        lds_bytes = (use_lds ? lds + lds_rm : 0) + (size_t)threads * sizeof(ScratchEnt);
         P.sites_per_block *= 2;
         chunks = (c->M + P.sites_per_block - 1) / P.sites_per_block;
         blocks = chunks * c->nslices;
