@@ -68,6 +68,7 @@ constexpr int WAVE = 64;
 constexpr int SCAN_THREADS = 256;             // 4 waves per workgroup (default)
 constexpr int SCAN_THREADS_MAX = 512;         // 8 waves when one R slice fills most of a CU's LDS
 constexpr int LDS_LIMIT_BYTES = 160 * 1024;   // gfx950: 160 KiB per CU
+constexpr int MOM_SLOTS = 32;                 // grouped kernel: rows whose far-field sites are summed as moments
 constexpr double LN2 = 0.693147180559945309417232121458;
 
 // ----------------------------------------------------------------------------- K1
@@ -204,6 +205,11 @@ struct ScanParams {
     double rmax;       // max(0, largest finite R of the table)
     double far_eps;    // grouped kernel, FARSUM: sites with E * rowmax[row] <= far_eps go through power sums
     const double *rowmax;  // [nslices][rows]: max |R| of the row over the slice's 64 pairs (+inf for absent rows)
+    // far-field moments of the most frequent rows (FARSUM): slot_of_row[row] = rank of the row among the
+    // data's rows by frequency (255: not ranked), row_of_slot its inverse, kmom[iA] how many slots pay at A
+    const uint8_t *slot_of_row;
+    const uint8_t *kmom;
+    int row_of_slot[MOM_SLOTS];
     float far_bits;    // far_eps * log2(e): exponent-budget bits per far site
     int sites_per_block;
     double *part_T;    // [nslices][M]
@@ -408,8 +414,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
         const int total = P.rows * WAVE;
         for (int idx = threadIdx.x; idx < total; idx += blockDim.x)
             lds_R[idx] = P.Rt[(size_t)(idx >> 6) * P.NP + slice * WAVE + (idx & 63)];
-        for (int idx = threadIdx.x; idx < P.rows; idx += blockDim.x)
+        for (int idx = threadIdx.x; idx < P.rows; idx += blockDim.x) {
             lds_R[total + idx] = P.rowmax[(size_t)slice * P.rows + idx];
+            reinterpret_cast<uint8_t *>(lds_R + total + ((P.rows + 1) & ~1))[idx] = P.slot_of_row[idx];
+        }
         __syncthreads();
     }
     const double *Rg = P.Rt + slice * WAVE + lane;
@@ -417,9 +425,18 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
         return USE_LDS ? lds_R[rowoff + lane] : Rg[(size_t)(rowoff >> 6) * P.NP];
     };
     // per-row max |R| of this slice (behind the R slice), then the wave-private scratch: 64 x 16 B
-    const int rows_pad = (P.rows + 1) & ~1;
+    // then the rows' moment slots (1 B each), the wave-private scratch (64 x 16 B per wave) and the
+    // wave-private moments (MOM_SLOTS x 4 doubles per wave)
+    const int rows_pad = (P.rows + 1) & ~1, slot_pad = ((P.rows + 15) & ~15) / 8;   // in doubles
     const double *rowmax = USE_LDS ? lds_R + P.rows * WAVE : P.rowmax + (size_t)slice * P.rows;
-    ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_R + (USE_LDS ? P.rows * WAVE + rows_pad : 0)) + wave * WAVE;
+    const uint8_t *slot_tab = USE_LDS ? reinterpret_cast<const uint8_t *>(lds_R + P.rows * WAVE + rows_pad) : P.slot_of_row;
+    double *lds_tail = lds_R + (USE_LDS ? P.rows * WAVE + rows_pad + slot_pad : 0);
+    ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_tail) + wave * WAVE;
+    double *mom = lds_tail + (blockDim.x / WAVE) * WAVE * 2 + wave * (MOM_SLOTS * 4);
+    if (MODE_ == 3) {
+        for (int idx = lane; idx < MOM_SLOTS * 4; idx += WAVE) mom[idx] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+    }
     double *scr_d = reinterpret_cast<double *>(scr);
 
     const int64_t ngroups = (P.M + J - 1) / J;
@@ -452,6 +469,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 
         for (int iA = 0; iA < P.nA; ++iA) {
             const double A = P.A[iA];
+            const int kmom = MODE_ == 3 ? (int)P.kmom[iA] : 0;
             // Exponent budget: every factor 1 + alpha*R lies in [1 - alpha, max(1, 1 + Rmax)], so a
             // block of 8 sites moves log2 of a product by at most 8*span bits, span being the
             // larger of span_hi and -log2(1 - alpha_max).  The products are pulled back to [1,2)
@@ -561,24 +579,44 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             // FARSUM: a site is far when alpha*|R| <= far_eps for every pair of the slice and every
                             // test site (alpha = E F <= E).  Far sites go through the power sums and are listed
                             // behind the near ones in the scratch; the block loops only see the near list.
-                            bool farl = false;
-                            int nfar = 0, pos = lane;
+                            // Far sites of the kmom most frequent rows (the bulk of them: substitutions, singletons,
+                            // ...) are not even listed: lane-parallel, their E, E^2, E^3, E^4 are added to the
+                            // row's moments in LDS, and the zone's end turns the moments into the same power sums
+                            // (p_k += M_k[row] * R[row]^k) at a cost that does not depend on the number of sites.
+                            bool farl = false, moml = false;
+                            int nfar = 0, nlist = 0, pos = lane;
                             if (FARSUM) {
                                 farl = bulk && Ev * rowmax[rraw] <= P.far_eps && nfar_tot < 65536;   // see the bound below
                                 const unsigned long long mf = __ballot(farl);
                                 nfar = __popcll(mf);
                                 if (nfar) {
-                                    const unsigned long long mn = mb & ~mf;
-                                    const int rf = __builtin_amdgcn_mbcnt_hi((unsigned)(mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mf, 0u));
-                                    const int rn = __builtin_amdgcn_mbcnt_hi((unsigned)(mn >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mn, 0u));
-                                    pos = farl ? cnt - nfar + rf : (bulk ? rn : lane);   // lanes past the bulk prefix keep their slot
+                                    const int slot = slot_tab[rraw];
+                                    moml = farl && slot < kmom;
+                                    const unsigned long long mm = __ballot(moml);
+                                    if (moml) {
+                                        double *mr = mom + slot * 4;
+                                        const double E2 = Ev * Ev;
+                                        atomicAdd(mr, Ev);
+                                        atomicAdd(mr + 1, E2);
+                                        atomicAdd(mr + 2, E2 * Ev);
+                                        atomicAdd(mr + 3, E2 * E2);
+                                    }
+                                    const unsigned long long ml = mf & ~mm, mn = mb & ~mf;
+                                    nlist = __popcll(ml);
+                                    const int nnear = cnt - nfar;
+                                    auto rank = [&](unsigned long long m) {
+                                        return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                                    };
+                                    // scratch: [near | listed far | moment lanes (E = 0) | lanes past the bulk prefix]
+                                    pos = moml ? nnear + nlist + rank(mm) : farl ? nnear + rank(ml) : bulk ? rank(mn) : lane;
                                 }
                             }
-                            scr[pos] = ScratchEnt{Ev, rowoff, 0};
+                            scr[pos] = ScratchEnt{moml ? 0.0 : Ev, rowoff, 0};
                             __builtin_amdgcn_wave_barrier();
                             if (FARSUM && nfar) {
+                                const int lend = cnt - nfar + nlist;
                                 int l = cnt - nfar;
-                                for (; l + 4 <= cnt; l += 4) {
+                                for (; l + 4 <= lend; l += 4) {
                                     double v[4];
 #pragma unroll
                                     for (int u = 0; u < 4; ++u) {
@@ -594,7 +632,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                         p4 = fma(v2, v2, p4);
                                     }
                                 }
-                                for (; l < cnt; ++l) {
+                                for (; l < lend; ++l) {
                                     const ScratchEnt en = scr[l];
                                     const double v = en.e * loadR(en.ro), v2 = v * v;
                                     p1 += v;
@@ -603,9 +641,11 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                     p4 = fma(v2, v2, p4);
                                 }
                                 nfar_tot += nfar;
-                                __builtin_amdgcn_wave_barrier();
-                                if (farl) scr[pos].e = 0.0;            // the block loops below see factor 1
-                                __builtin_amdgcn_wave_barrier();
+                                if (nlist) {
+                                    __builtin_amdgcn_wave_barrier();
+                                    if (farl && !moml) scr[pos].e = 0.0;   // the block loops below see factor 1
+                                    __builtin_amdgcn_wave_barrier();
+                                }
                                 cnt_blk = cnt - nfar;
                             }
                             constexpr int BS = J >= 16 ? 4 : 8;        // sites per unrolled block
@@ -671,6 +711,22 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     base += dir * cnt;
                     if (cnt < WAVE) break;
                     i = inx;
+                }
+                if (FARSUM && nfar_tot && kmom) {
+                    // moments of the frequent rows -> the same power sums: p_k += M_k[row] * R[row]^k
+                    __builtin_amdgcn_wave_barrier();
+                    for (int sl_ = 0; sl_ < kmom; ++sl_) {
+                        double2 *mp = reinterpret_cast<double2 *>(mom + sl_ * 4);
+                        const double2 ma = mp[0], mc = mp[1];             // uniform address: LDS broadcast
+                        const double R = loadR(P.row_of_slot[sl_] * WAVE), R2 = R * R;
+                        p1 = fma(ma.x, R, p1);
+                        p2 = fma(ma.y, R2, p2);
+                        p3 = fma(mc.x, R2 * R, p3);
+                        p4 = fma(mc.y, R2 * R2, p4);
+                        mp[0] = double2{0.0, 0.0};                       // ready for the next zone
+                        mp[1] = double2{0.0, 0.0};
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
                 if (FARSUM && nfar_tot) {
                     // sum_i log1p(F v_i) = F p1 - F^2 p2/2 + F^3 p3/3 - F^4 p4/4 + ...  with
@@ -860,6 +916,10 @@ struct bmx_ctx {
     int32_t *d_sizes = nullptr, *d_row_off = nullptr;
     double *d_g = nullptr, *d_prop = nullptr, *d_x = nullptr, *d_abeta = nullptr, *d_A = nullptr;
     double *d_psel = nullptr, *d_R = nullptr, *d_Rt = nullptr, *d_rowmax = nullptr;
+    std::vector<double> h_A;
+    // far-field moment slots: the data's most frequent rows (set_sites)
+    uint8_t *d_slot_of_row = nullptr, *d_kmom = nullptr;
+    int row_of_slot[MOM_SLOTS] = {0};
     uint64_t *d_patch_x = nullptr;
     double *d_patch_y = nullptr;
     int n_patch = 0;
@@ -893,7 +953,7 @@ void free_model(bmx_ctx *c) {
     c->has_model = false;
 }
 void free_sites(bmx_ctx *c) {
-    dfree(c->d_genpos); dfree(c->d_row); dfree(c->d_row32);
+    dfree(c->d_genpos); dfree(c->d_row); dfree(c->d_row32); dfree(c->d_slot_of_row); dfree(c->d_kmom);
     c->has_sites = false;
 }
 void free_tests(bmx_ctx *c) {
@@ -1015,6 +1075,7 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     if ((rc = upload(c->d_x, m->x, (size_t)m->nx, c->stream))) return rc;
     if ((rc = upload(c->d_abeta, m->abeta, (size_t)m->nab, c->stream))) return rc;
     if ((rc = upload(c->d_A, A, (size_t)nA, c->stream))) return rc;
+    c->h_A.assign(A, A + nA);
     size_t tab = (size_t)c->npairs * c->rows;
     HIP_TRY(hipMalloc((void **)&c->d_psel, tab * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_R, tab * sizeof(double)));
@@ -1134,6 +1195,39 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
     } else {
         if ((rc = upload(c->d_row, (const uint16_t *)r16.data(), (size_t)N, c->stream))) return rc;
     }
+    {
+        // Moment slots for the grouped kernel's far field: rank the rows by how many sites carry them.
+        // Slot s pays at a given A when the ~7.5 instructions saved per far site of that row outweigh
+        // the ~16 instructions its term costs at the end of each zone; the expected number of far sites
+        // per zone follows from the mean site density (a performance heuristic only: any choice is exact).
+        std::vector<int64_t> cnt((size_t)c->rows, 0);
+        for (int64_t i = 0; i < N; i++) cnt[(size_t)row[i]]++;
+        std::vector<int> order((size_t)c->rows);
+        for (int r = 0; r < c->rows; r++) order[(size_t)r] = r;
+        const size_t ns = std::min((size_t)MOM_SLOTS, order.size());
+        std::partial_sort(order.begin(), order.begin() + ns, order.end(),
+                          [&](int a, int b) { return cnt[(size_t)a] != cnt[(size_t)b] ? cnt[(size_t)a] > cnt[(size_t)b] : a < b; });
+        std::vector<uint8_t> slot((size_t)c->rows, 255);
+        int nslots = 0;
+        for (size_t k = 0; k < ns; k++) {
+            if (cnt[(size_t)order[k]] == 0) break;
+            slot[(size_t)order[k]] = (uint8_t)k;
+            c->row_of_slot[k] = order[k];
+            nslots = (int)k + 1;
+        }
+        for (int k = nslots; k < MOM_SLOTS; k++) c->row_of_slot[k] = nslots ? c->row_of_slot[0] : 0;
+        const int kcap = getenv("BMX_MOM_SLOTS") ? std::min(atoi(getenv("BMX_MOM_SLOTS")), MOM_SLOTS) : MOM_SLOTS;   // experiments
+        const double range = genpos[N - 1] - genpos[0];
+        std::vector<uint8_t> km((size_t)c->nA, 0);
+        for (int a = 0; a < c->nA; a++) {
+            const double nfar = range > 0 ? 0.6 * (double)(N - 1) / range * c->zcut / c->h_A[(size_t)a] : (double)N;
+            int k = 0;
+            while (k < nslots && k < kcap && (double)cnt[(size_t)c->row_of_slot[k]] / (double)N * nfar * 7.5 > 16.0) k++;
+            km[(size_t)a] = (uint8_t)k;
+        }
+        if ((rc = upload(c->d_slot_of_row, (const uint8_t *)slot.data(), slot.size(), c->stream))) return rc;
+        if ((rc = upload(c->d_kmom, (const uint8_t *)km.data(), km.size(), c->stream))) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->N = N;
     c->has_sites = true;
@@ -1200,12 +1294,15 @@ int bmx_ctx_scan(bmx_ctx *c) {
         eps = std::min(std::max(eps, 0.0), 1e-2);
         P.far_eps = eps;
         P.rowmax = c->d_rowmax;
+        P.slot_of_row = c->d_slot_of_row; P.kmom = c->d_kmom;
+        for (int k = 0; k < MOM_SLOTS; k++) P.row_of_slot[k] = c->row_of_slot[k];
         P.far_bits = (float)(eps * 1.4427);
     }
     P.part_T = c->d_part_T; P.part_lin = c->d_part_lin; P.part_ns = c->d_part_ns;
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
     if (const char *pad = getenv("BMX_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
-    const bool fits = lds + (size_t)(c->rows + 2) * sizeof(double) + (size_t)SCAN_THREADS_MAX * sizeof(ScratchEnt) <= (size_t)LDS_LIMIT_BYTES;
+    const bool fits = lds + (size_t)(c->rows + 2) * sizeof(double) + (size_t)(c->rows + 16) +
+                      (size_t)(SCAN_THREADS_MAX / WAVE) * (WAVE * sizeof(ScratchEnt) + MOM_SLOTS * 4 * sizeof(double)) <= (size_t)LDS_LIMIT_BYTES;
     // grouping pays when neighbouring test sites share most of their windows; a strided scan
     // (-s far larger than 1) is better served one test site per wave
     // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3
@@ -1248,11 +1345,13 @@ int bmx_ctx_scan(bmx_ctx *c) {
     // One wave per SIMD issues FP64 at half rate (measured), so a workgroup whose LDS footprint
     // allows only one resident workgroup per CU gets 8 waves instead of 4.
     int threads = SCAN_THREADS;
-    const size_t lds_rm = (size_t)((c->rows + 1) & ~1) * sizeof(double);    // grouped kernels: per-row max |R| behind the slice
-    size_t lds_bytes = (use_lds ? lds + (J ? lds_rm : 0) : 0) + (J ? (size_t)threads * sizeof(ScratchEnt) : 0);
+    // grouped kernels: per-row max |R| and moment slots behind the slice, moments behind the scratch
+    const size_t lds_rm = (size_t)((c->rows + 1) & ~1) * sizeof(double) + (size_t)((c->rows + 15) & ~15);
+    const size_t lds_wave = WAVE * sizeof(ScratchEnt) + MOM_SLOTS * 4 * sizeof(double);
+    size_t lds_bytes = (use_lds ? lds + (J ? lds_rm : 0) : 0) + (J ? (size_t)(threads / WAVE) * lds_wave : 0);
     if (J && 2 * lds_bytes > (size_t)LDS_LIMIT_BYTES) {
         threads = SCAN_THREADS_MAX;
-        lds_bytes = (use_lds ? lds + lds_rm : 0) + (size_t)threads * sizeof(ScratchEnt);
+        lds_bytes = (use_lds ? lds + lds_rm : 0) + (size_t)(threads / WAVE) * lds_wave;
         P.sites_per_block *= 2;
         chunks = (c->M + P.sites_per_block - 1) / P.sites_per_block;
         blocks = chunks * c->nslices;

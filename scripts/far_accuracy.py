@@ -29,9 +29,13 @@ def run(variant, eps=None):
     ctx.set_variant(variant)
     ctx.set_tests(gen[idx], lo, hi)
     ctx.scan(); ctx.sync()
+    first = [a.copy() for a in ctx.fetch()]
     ctx.scan(); ctx.sync()
     ms = ctx.last_scan_ms()
-    return [a.copy() for a in ctx.fetch()], ms
+    out = [a.copy() for a in ctx.fetch()]
+    if not all(np.array_equal(a, b) for a, b in zip(first, out)):
+        print('  !! two scans of the same input differ bitwise (variant %d)' % variant)
+    return out, ms
 
 base, ms0 = run(10)
 print('variant 10 (exact products): %.1f ms' % ms0)
