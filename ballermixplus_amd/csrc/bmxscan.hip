@@ -68,7 +68,16 @@ constexpr int WAVE = 64;
 constexpr int SCAN_THREADS = 256;             // 4 waves per workgroup (default)
 constexpr int SCAN_THREADS_MAX = 512;         // 8 waves when one R slice fills most of a CU's LDS
 constexpr int LDS_LIMIT_BYTES = 160 * 1024;   // gfx950: 160 KiB per CU
-constexpr int MOM_SLOTS = 32;                 // grouped kernel: rows whose far-field sites are summed as moments
+constexpr int MOM_SLOTS = 64;                 // grouped kernel: rows whose far-field sites are summed as moments
+#ifndef BMX_FAR_ORDER
+#define BMX_FAR_ORDER 6
+#endif
+constexpr int FAR_ORDER = BMX_FAR_ORDER;      // ... to this power of alpha*R (log1p series): 4, 6 or 8
+#ifndef BMX_MOM_COPIES
+#define BMX_MOM_COPIES 8
+#endif
+constexpr int MOM_COPIES = BMX_MOM_COPIES;                 // copies of the most frequent row's moments (lane % 8): fewer LDS conflicts
+constexpr int FAR_CAP = 16384;                // ... at most this many sites per zone (exponent budget)
 constexpr double LN2 = 0.693147180559945309417232121458;
 
 // ----------------------------------------------------------------------------- K1
@@ -210,6 +219,7 @@ struct ScanParams {
     const uint8_t *slot_of_row;
     const uint8_t *kmom;
     int row_of_slot[MOM_SLOTS];
+    int mom_slots;     // slots per wave allocated in LDS (<= MOM_SLOTS)
     float far_bits;    // far_eps * log2(e): exponent-budget bits per far site
     int sites_per_block;
     double *part_T;    // [nslices][M]
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
     extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then scratch
     constexpr int SP = WAVE / J;                                    // sites per generic pass
     constexpr bool QUAD = (MODE_ >= 2);                             // MODE_ 2 = MODE 1 + quads in far passes
-    constexpr bool FARSUM = (MODE_ == 3);                           // MODE_ 3 = MODE 2 + power sums in the far field
+    constexpr bool FARSUM = (MODE_ == 3);                           // MODE_ 3 = MODE 2 + far-field moments
     constexpr int MODE = MODE_ ? 1 : 0;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = threadIdx.x >> 6;
@@ -432,9 +442,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
     const uint8_t *slot_tab = USE_LDS ? reinterpret_cast<const uint8_t *>(lds_R + P.rows * WAVE + rows_pad) : P.slot_of_row;
     double *lds_tail = lds_R + (USE_LDS ? P.rows * WAVE + rows_pad + slot_pad : 0);
     ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_tail) + wave * WAVE;
-    double *mom = lds_tail + (blockDim.x / WAVE) * WAVE * 2 + wave * (MOM_SLOTS * 4);
+    const int mom_len = (P.mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER;   // slot 0 in MOM_COPIES copies, slots 1.., 3 spare
+    double *mom = lds_tail + (blockDim.x / WAVE) * WAVE * 2 + wave * mom_len;
     if (MODE_ == 3) {
-        for (int idx = lane; idx < MOM_SLOTS * 4; idx += WAVE) mom[idx] = 0.0;
+        for (int idx = lane; idx < mom_len; idx += WAVE) mom[idx] = 0.0;
         __builtin_amdgcn_wave_barrier();
     }
     double *scr_d = reinterpret_cast<double *>(scr);
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 
         for (int iA = 0; iA < P.nA; ++iA) {
             const double A = P.A[iA];
-            const int kmom = MODE_ == 3 ? (int)P.kmom[iA] : 0;
+            const int kmom = MODE_ == 3 ? min((int)P.kmom[iA], P.mom_slots) : 0;
             // Exponent budget: every factor 1 + alpha*R lies in [1 - alpha, max(1, 1 + Rmax)], so a
             // block of 8 sites moves log2 of a product by at most 8*span bits, span being the
             // larger of span_hi and -log2(1 - alpha_max).  The products are pulled back to [1,2)
@@ -548,9 +559,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                 int i = base + dir * lane;
                 double g_nx = P.genpos[min(max(i, 0), N - 1)];
                 int r_nx = (int)P.row[min(max(i, 0), N - 1)];
-                // far field (FARSUM): power sums p_k = sum v^k of the sites whose E <= far_theta, per lane
-                double p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
-                int nfar_tot = 0;
+                int nfar_tot = 0;                                  // far-field sites of this zone (FARSUM)
                 while (true) {
                     const bool ok = dir > 0 ? (i <= hi_min) : (i >= lo_max);
                     const double g = g_nx;
@@ -576,78 +585,51 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                         const int span8 = 8 * min(max(hibits, lowbits), 125);
                         int cnt_blk = cnt;                              // sites left to the block loops
                         if (MODE == 1) {
-                            // FARSUM: a site is far when alpha*|R| <= far_eps for every pair of the slice and every
-                            // test site (alpha = E F <= E).  Far sites go through the power sums and are listed
-                            // behind the near ones in the scratch; the block loops only see the near list.
-                            // Far sites of the kmom most frequent rows (the bulk of them: substitutions, singletons,
-                            // ...) are not even listed: lane-parallel, their E, E^2, E^3, E^4 are added to the
-                            // row's moments in LDS, and the zone's end turns the moments into the same power sums
-                            // (p_k += M_k[row] * R[row]^k) at a cost that does not depend on the number of sites.
-                            bool farl = false, moml = false;
-                            int nfar = 0, nlist = 0, pos = lane;
-                            if (FARSUM) {
-                                farl = bulk && Ev * rowmax[rraw] <= P.far_eps && nfar_tot < 65536;   // see the bound below
-                                const unsigned long long mf = __ballot(farl);
-                                nfar = __popcll(mf);
+                            // FARSUM.  A site is FAR when alpha*|R| <= far_eps for every pair of the slice and every
+                            // test site (alpha = E F <= E) and its row is one of the kmom most frequent rows of the
+                            // data (substitutions, singletons, ...: nearly all sites).  For those,
+                            //   sum_i log1p(F v_i) = sum_k (-1)^(k+1) F^k/k * sum_rows R[row]^k M_k[row],  M_k = sum_i E_i^k,
+                            // so the pass only adds E, E^2, .. E^8 to the row's moments in LDS -- lane-parallel over
+                            // the sites, nothing per pair -- and the zone's end folds the moments into the product.
+                            // Far lanes leave a neutral entry (E = 0) behind the near list of the scratch.
+                            bool moml = false;
+                            int pos = lane;
+                            if (FARSUM && kmom) {
+                                const int slot = slot_tab[rraw];
+                                moml = bulk && slot < kmom && Ev * rowmax[rraw] <= P.far_eps && nfar_tot < FAR_CAP;
+                                const unsigned long long mm = __ballot(moml);
+                                const int nfar = __popcll(mm);
                                 if (nfar) {
-                                    const int slot = slot_tab[rraw];
-                                    moml = farl && slot < kmom;
-                                    const unsigned long long mm = __ballot(moml);
                                     if (moml) {
-                                        double *mr = mom + slot * 4;
-                                        const double E2 = Ev * Ev;
+                                        // most sites carry the most frequent row (substitutions): its moments are kept in
+                                        // MOM_COPIES copies so that one ds_add_f64 does not serialise ~45 lanes on one address
+                                        double *mr = mom + (slot ? slot + MOM_COPIES - 1 : (lane & (MOM_COPIES - 1))) * FAR_ORDER;   // slot 0 = copies 0..C-1
+                                        const double E2 = Ev * Ev, E4 = E2 * E2, E3 = E2 * Ev;
                                         atomicAdd(mr, Ev);
                                         atomicAdd(mr + 1, E2);
-                                        atomicAdd(mr + 2, E2 * Ev);
-                                        atomicAdd(mr + 3, E2 * E2);
+                                        atomicAdd(mr + 2, E3);
+                                        atomicAdd(mr + 3, E4);
+                                        if constexpr (FAR_ORDER >= 6) {
+                                            atomicAdd(mr + 4, E4 * Ev);
+                                            atomicAdd(mr + 5, E4 * E2);
+                                        }
+                                        if constexpr (FAR_ORDER >= 8) {
+                                            atomicAdd(mr + 6, E4 * E3);
+                                            atomicAdd(mr + 7, E4 * E4);
+                                        }
                                     }
-                                    const unsigned long long ml = mf & ~mm, mn = mb & ~mf;
-                                    nlist = __popcll(ml);
-                                    const int nnear = cnt - nfar;
+                                    const unsigned long long mn = mb & ~mm;
                                     auto rank = [&](unsigned long long m) {
                                         return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                                     };
-                                    // scratch: [near | listed far | moment lanes (E = 0) | lanes past the bulk prefix]
-                                    pos = moml ? nnear + nlist + rank(mm) : farl ? nnear + rank(ml) : bulk ? rank(mn) : lane;
+                                    // scratch: [near | far lanes (E = 0) | lanes past the bulk prefix]
+                                    pos = moml ? cnt - nfar + rank(mm) : bulk ? rank(mn) : lane;
+                                    nfar_tot += nfar;
+                                    cnt_blk = cnt - nfar;
                                 }
                             }
                             scr[pos] = ScratchEnt{moml ? 0.0 : Ev, rowoff, 0};
                             __builtin_amdgcn_wave_barrier();
-                            if (FARSUM && nfar) {
-                                const int lend = cnt - nfar + nlist;
-                                int l = cnt - nfar;
-                                for (; l + 4 <= lend; l += 4) {
-                                    double v[4];
-#pragma unroll
-                                    for (int u = 0; u < 4; ++u) {
-                                        const ScratchEnt en = scr[l + u];
-                                        v[u] = en.e * loadR(en.ro);
-                                    }
-#pragma unroll
-                                    for (int u = 0; u < 4; ++u) {
-                                        const double v2 = v[u] * v[u];
-                                        p1 += v[u];
-                                        p2 += v2;
-                                        p3 = fma(v2, v[u], p3);
-                                        p4 = fma(v2, v2, p4);
-                                    }
-                                }
-                                for (; l < lend; ++l) {
-                                    const ScratchEnt en = scr[l];
-                                    const double v = en.e * loadR(en.ro), v2 = v * v;
-                                    p1 += v;
-                                    p2 += v2;
-                                    p3 = fma(v2, v, p3);
-                                    p4 = fma(v2, v2, p4);
-                                }
-                                nfar_tot += nfar;
-                                if (nlist) {
-                                    __builtin_amdgcn_wave_barrier();
-                                    if (farl && !moml) scr[pos].e = 0.0;   // the block loops below see factor 1
-                                    __builtin_amdgcn_wave_barrier();
-                                }
-                                cnt_blk = cnt - nfar;
-                            }
                             constexpr int BS = J >= 16 ? 4 : 8;        // sites per unrolled block
                             // Far passes (every alpha <= 1/2: factors >= 1/2, the expanded product is well
                             // conditioned) can take FOUR sites per step:
@@ -712,34 +694,81 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     if (cnt < WAVE) break;
                     i = inx;
                 }
-                if (FARSUM && nfar_tot && kmom) {
-                    // moments of the frequent rows -> the same power sums: p_k += M_k[row] * R[row]^k
+                if (FARSUM && nfar_tot) {
+                    // fold the moments: p_k = sum_rows M_k[row] R[row]^k, then acc_j *= exp(sum_k (-1)^(k+1) F_j^k p_k / k).
+                    // |F v| <= far_eps = 0.03: the series is cut at |x|^9/9 < 2.2e-15 for the nearest far site
+                    // and e^-9 of that per further unit of A*d.  |sum| <= nfar_tot * far_eps * 1.02 < 510.
                     __builtin_amdgcn_wave_barrier();
-                    for (int sl_ = 0; sl_ < kmom; ++sl_) {
-                        double2 *mp = reinterpret_cast<double2 *>(mom + sl_ * 4);
-                        const double2 ma = mp[0], mc = mp[1];             // uniform address: LDS broadcast
-                        const double R = loadR(P.row_of_slot[sl_] * WAVE), R2 = R * R;
-                        p1 = fma(ma.x, R, p1);
-                        p2 = fma(ma.y, R2, p2);
-                        p3 = fma(mc.x, R2 * R, p3);
-                        p4 = fma(mc.y, R2 * R2, p4);
-                        mp[0] = double2{0.0, 0.0};                       // ready for the next zone
-                        mp[1] = double2{0.0, 0.0};
+                    double p[FAR_ORDER];
+#pragma unroll
+                    for (int k = 0; k < FAR_ORDER; ++k) p[k] = 0.0;
+                    auto fold = [&](const double (&m)[FAR_ORDER], int slot) {
+                        const double R = loadR(P.row_of_slot[slot] * WAVE);
+                        const double R2 = R * R, R3 = R2 * R, R4 = R2 * R2;
+                        p[0] = fma(m[0], R, p[0]);
+                        p[1] = fma(m[1], R2, p[1]);
+                        p[2] = fma(m[2], R3, p[2]);
+                        p[3] = fma(m[3], R4, p[3]);
+                        if constexpr (FAR_ORDER >= 6) {
+                            p[4] = fma(m[4], R4 * R, p[4]);
+                            p[5] = fma(m[5], R4 * R2, p[5]);
+                        }
+                        if constexpr (FAR_ORDER >= 8) {
+                            p[6] = fma(m[6], R4 * R3, p[6]);
+                            p[7] = fma(m[7], R4 * R4, p[7]);
+                        }
+                    };
+                    {   // slot 0: its MOM_COPIES copies are read lane-parallel (copy = lane / order, moment = lane % order)
+                        // and added up across lanes
+                        static_assert(MOM_COPIES * FAR_ORDER <= WAVE, "slot-0 copies must fit one wave-wide read");
+                        double x = 0.0;
+                        if (lane < MOM_COPIES * FAR_ORDER) {
+                            x = mom[lane];
+                            mom[lane] = 0.0;                              // ready for the next zone
+                        }
+#pragma unroll
+                        for (int c = MOM_COPIES / 2; c >= 1; c >>= 1) x += __shfl_down(x, c * FAR_ORDER);
+                        double m[FAR_ORDER];
+#pragma unroll
+                        for (int k = 0; k < FAR_ORDER; ++k) m[k] = readlane_f64(x, k);
+                        if (m[0] != 0.0) fold(m, 0);
+                    }
+                    // the other slots, four at a time: all LDS reads of a batch are in flight together
+                    for (int s0 = 1; s0 < kmom; s0 += 4) {
+                        double2 m2[4][FAR_ORDER / 2];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            double2 *mp = reinterpret_cast<double2 *>(mom + (s0 + u + MOM_COPIES - 1) * FAR_ORDER);
+#pragma unroll
+                            for (int q = 0; q < FAR_ORDER / 2; ++q) m2[u][q] = mp[q];    // uniform address: LDS broadcast
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (m2[u][0].x == 0.0) continue;              // no far site of this row in the zone
+                            double2 *mp = reinterpret_cast<double2 *>(mom + (s0 + u + MOM_COPIES - 1) * FAR_ORDER);
+                            double m[FAR_ORDER];
+#pragma unroll
+                            for (int q = 0; q < FAR_ORDER / 2; ++q) {
+                                m[2 * q] = m2[u][q].x;
+                                m[2 * q + 1] = m2[u][q].y;
+                                mp[q] = double2{0.0, 0.0};               // ready for the next zone
+                            }
+                            fold(m, min(s0 + u, MOM_SLOTS - 1));
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();
-                }
-                if (FARSUM && nfar_tot) {
-                    // sum_i log1p(F v_i) = F p1 - F^2 p2/2 + F^3 p3/3 - F^4 p4/4 + ...  with
-                    // |F v_i| <= E_i rowmax <= far_eps.  Dropped: < far_eps^5/5 for the nearest far site and
-                    // e^-5 of that per further unit of A*d, i.e. ~far_eps^5/25 times the number of sites per
-                    // unit of A*d (135 for config 3 at A = 100): 2e-12 if every R were max|R|; measured
-                    // 1e-14.  |sum| <= nfar_tot*far_eps < 656, inside exp's range and the exponent budget.
                     spend(2 + (int)((float)nfar_tot * P.far_bits));
-                    const double h2 = 0.5 * p2, h3 = p3 * 0.3333333333333333, h4 = 0.25 * p4;
+                    // t = p1 - f (p2/2 - f (p3/3 - ...)),  log product = f t
+                    constexpr double inv[8] = {1.0, 0.5, 0.3333333333333333, 0.25, 0.2, 0.16666666666666666, 0.14285714285714285, 0.125};
+#pragma unroll
+                    for (int k = 1; k < FAR_ORDER; ++k) p[k] *= inv[k];
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
-                        const double t = F[j] * (p1 - F[j] * (h2 - F[j] * (h3 - F[j] * h4)));
-                        acc[j] *= exp_neg(-t);
+                        const double f = F[j];
+                        double t = p[FAR_ORDER - 1];
+#pragma unroll
+                        for (int k = FAR_ORDER - 2; k >= 0; --k) t = fma(-f, t, p[k]);
+                        acc[j] *= exp_neg(-f * t);
                     }
                 }
                 return base;
@@ -1197,8 +1226,8 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
     }
     {
         // Moment slots for the grouped kernel's far field: rank the rows by how many sites carry them.
-        // Slot s pays at a given A when the ~7.5 instructions saved per far site of that row outweigh
-        // the ~16 instructions its term costs at the end of each zone; the expected number of far sites
+        // Slot s pays at a given A when the ~23 instructions saved per far site of that row outweigh
+        // the ~30 instructions its term costs at the end of each zone; the expected number of far sites
         // per zone follows from the mean site density (a performance heuristic only: any choice is exact).
         std::vector<int64_t> cnt((size_t)c->rows, 0);
         for (int64_t i = 0; i < N; i++) cnt[(size_t)row[i]]++;
@@ -1220,9 +1249,9 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
         const double range = genpos[N - 1] - genpos[0];
         std::vector<uint8_t> km((size_t)c->nA, 0);
         for (int a = 0; a < c->nA; a++) {
-            const double nfar = range > 0 ? 0.6 * (double)(N - 1) / range * c->zcut / c->h_A[(size_t)a] : (double)N;
+            const double nfar = range > 0 ? 0.8 * (double)(N - 1) / range * c->zcut / c->h_A[(size_t)a] : (double)N;
             int k = 0;
-            while (k < nslots && k < kcap && (double)cnt[(size_t)c->row_of_slot[k]] / (double)N * nfar * 7.5 > 16.0) k++;
+            while (k < nslots && k < kcap && (double)cnt[(size_t)c->row_of_slot[k]] / (double)N * nfar * 23.0 > 30.0) k++;
             km[(size_t)a] = (uint8_t)k;
         }
         if ((rc = upload(c->d_slot_of_row, (const uint8_t *)slot.data(), slot.size(), c->stream))) return rc;
@@ -1290,19 +1319,29 @@ int bmx_ctx_scan(bmx_ctx *c) {
     P.A = c->d_A; P.nA = c->nA; P.test_gen = c->d_test_gen; P.win_lo = c->d_win_lo; P.win_hi = c->d_win_hi;
     P.center = c->d_center; P.center_hi = c->d_center_hi; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi; P.rmax = c->rmax;
     {
-        double eps = getenv("BMX_FAR_EPS") ? atof(getenv("BMX_FAR_EPS")) : 2e-3;   // accuracy experiments
-        eps = std::min(std::max(eps, 0.0), 1e-2);
+        // series cut at |x|^(order+1)/(order+1) <= ~6e-15 for the nearest far site
+        const double eps_default = FAR_ORDER >= 8 ? 0.03 : FAR_ORDER >= 6 ? 0.0115 : 0.002;
+        double eps = getenv("BMX_FAR_EPS") ? atof(getenv("BMX_FAR_EPS")) : eps_default;   // accuracy experiments
+        eps = std::min(std::max(eps, 0.0), 0.035);
         P.far_eps = eps;
         P.rowmax = c->d_rowmax;
         P.slot_of_row = c->d_slot_of_row; P.kmom = c->d_kmom;
         for (int k = 0; k < MOM_SLOTS; k++) P.row_of_slot[k] = c->row_of_slot[k];
-        P.far_bits = (float)(eps * 1.4427);
+        P.far_bits = (float)(eps * 1.4427 * 1.02);      // |log1p(x)| <= 1.02 |x| for |x| <= 0.035
     }
     P.part_T = c->d_part_T; P.part_lin = c->d_part_lin; P.part_ns = c->d_part_ns;
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
     if (const char *pad = getenv("BMX_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
-    const bool fits = lds + (size_t)(c->rows + 2) * sizeof(double) + (size_t)(c->rows + 16) +
-                      (size_t)(SCAN_THREADS_MAX / WAVE) * (WAVE * sizeof(ScratchEnt) + MOM_SLOTS * 4 * sizeof(double)) <= (size_t)LDS_LIMIT_BYTES;
+    // moment slots per wave: as many (64, 32, 16, 8, 0) as leave the R slice in LDS
+    int mom_slots = MOM_SLOTS;
+    auto lds_need = [&](int slots) {
+        return lds + (size_t)(c->rows + 2) * sizeof(double) + (size_t)(c->rows + 16) +
+               (size_t)(SCAN_THREADS_MAX / WAVE) * (WAVE * sizeof(ScratchEnt) + (size_t)(slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double));
+    };
+    while (mom_slots >= 8 && lds_need(mom_slots) > (size_t)LDS_LIMIT_BYTES) mom_slots /= 2;
+    if (mom_slots < 8) mom_slots = 0;
+    const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES;
+    P.mom_slots = mom_slots;
     // grouping pays when neighbouring test sites share most of their windows; a strided scan
     // (-s far larger than 1) is better served one test site per wave
     // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3
@@ -1347,7 +1386,7 @@ int bmx_ctx_scan(bmx_ctx *c) {
     int threads = SCAN_THREADS;
     // grouped kernels: per-row max |R| and moment slots behind the slice, moments behind the scratch
     const size_t lds_rm = (size_t)((c->rows + 1) & ~1) * sizeof(double) + (size_t)((c->rows + 15) & ~15);
-    const size_t lds_wave = WAVE * sizeof(ScratchEnt) + MOM_SLOTS * 4 * sizeof(double);
+    const size_t lds_wave = WAVE * sizeof(ScratchEnt) + (size_t)(mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double);
     size_t lds_bytes = (use_lds ? lds + (J ? lds_rm : 0) : 0) + (J ? (size_t)(threads / WAVE) * lds_wave : 0);
     if (J && 2 * lds_bytes > (size_t)LDS_LIMIT_BYTES) {
         threads = SCAN_THREADS_MAX;

@@ -135,7 +135,7 @@ def test_full_size_properties_config3():
     """Config 3 (1M SNPs, n=100, default grid) at full size, through properties that need no
     reference run: (i) a strided subset scanned alone equals the same rows of a denser scan
     (shard invariance: what multi-GPU sharding relies on); (ii) windows fully inside a 60k-site
-    sub-chromosome give bit-identical rows when that sub-chromosome is scanned on its own;
+    sub-chromosome give the same rows (CLR to rounding) when that sub-chromosome is scanned on its own;
     (iii) the C oracle agrees on a sample of rows."""
     eng = _engine()
     N, n = 1000000, 100
@@ -183,8 +183,11 @@ def test_full_size_properties_config3():
     ctx2.set_tests(gen[idx], full_lo(len(idx)), np.full(len(idx), hi_c - lo_c - 1, np.int64))
     ctx2.scan()
     cut = ctx2.fetch()
-    for a, b in zip(dense, cut):
+    # a different site array ranks its rows afresh for the far-field moments (which rows are summed as
+    # moments is a per-array choice), so the CLR agrees to rounding, not bit for bit
+    for a, b in zip(dense[1:], cut[1:]):
         assert np.array_equal(a, b)
+    assert np.allclose(dense[0], cut[0], rtol=1e-10, atol=1e-13)
     # (iii) oracle on 24 rows
     L = c_oracle()
     _, R = ctx.fetch_lut()
