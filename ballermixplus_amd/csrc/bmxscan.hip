@@ -213,10 +213,10 @@ struct ScanParams {
     int span_hi;       // grouped kernel: bits by which one factor 1+alpha*R can exceed 1 (>= 1)
     double rmax;       // max(0, largest finite R of the table)
     double far_eps;    // grouped kernel, FARSUM: sites with E * rowmax[row] <= far_eps go through power sums
-    const double *rowmax;  // [nslices][rows]: max |R| of the row over the slice's 64 pairs (+inf for absent rows)
-    // far-field moments of the most frequent rows (FARSUM): slot_of_row[row] = rank of the row among the
-    // data's rows by frequency (255: not ranked), row_of_slot its inverse, kmom[iA] how many slots pay at A
-    const uint8_t *slot_of_row;
+    // [nslices][rows]: max |R| of the row over the slice's 64 pairs, rounded up (NaN for absent rows), with the
+    // row's far-field moment slot in the low mantissa byte: the rank of the row among the data's rows by
+    // frequency (255: not ranked); row_of_slot is the inverse, kmom[iA] says how many slots pay at A
+    const double *rowmax;
     const uint8_t *kmom;
     int row_of_slot[MOM_SLOTS];
     int mom_slots;     // slots per wave allocated in LDS (<= MOM_SLOTS)
@@ -424,10 +424,8 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
         const int total = P.rows * WAVE;
         for (int idx = threadIdx.x; idx < total; idx += blockDim.x)
             lds_R[idx] = P.Rt[(size_t)(idx >> 6) * P.NP + slice * WAVE + (idx & 63)];
-        for (int idx = threadIdx.x; idx < P.rows; idx += blockDim.x) {
+        for (int idx = threadIdx.x; idx < P.rows; idx += blockDim.x)
             lds_R[total + idx] = P.rowmax[(size_t)slice * P.rows + idx];
-            reinterpret_cast<uint8_t *>(lds_R + total + ((P.rows + 1) & ~1))[idx] = P.slot_of_row[idx];
-        }
         __syncthreads();
     }
     const double *Rg = P.Rt + slice * WAVE + lane;
@@ -435,12 +433,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
         return USE_LDS ? lds_R[rowoff + lane] : Rg[(size_t)(rowoff >> 6) * P.NP];
     };
     // per-row max |R| of this slice (behind the R slice), then the wave-private scratch: 64 x 16 B
-    // then the rows' moment slots (1 B each), the wave-private scratch (64 x 16 B per wave) and the
-    // wave-private moments (MOM_SLOTS x 4 doubles per wave)
-    const int rows_pad = (P.rows + 1) & ~1, slot_pad = ((P.rows + 15) & ~15) / 8;   // in doubles
+    // then the wave-private scratch (64 x 16 B per wave) and the wave-private moments
+    const int rows_pad = (P.rows + 1) & ~1;
     const double *rowmax = USE_LDS ? lds_R + P.rows * WAVE : P.rowmax + (size_t)slice * P.rows;
-    const uint8_t *slot_tab = USE_LDS ? reinterpret_cast<const uint8_t *>(lds_R + P.rows * WAVE + rows_pad) : P.slot_of_row;
-    double *lds_tail = lds_R + (USE_LDS ? P.rows * WAVE + rows_pad + slot_pad : 0);
+    double *lds_tail = lds_R + (USE_LDS ? P.rows * WAVE + rows_pad : 0);
     ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_tail) + wave * WAVE;
     const int mom_len = (P.mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER;   // slot 0 in MOM_COPIES copies, slots 1.., 3 spare
     double *mom = lds_tail + (blockDim.x / WAVE) * WAVE * 2 + wave * mom_len;
@@ -572,17 +568,6 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     const int cnt = __popcll(mb);
                     if (cnt) {
                         const double Ev = bulk ? exp_neg(A * fabs(g - tnear)) : 0.0;
-                        // lanes past the bulk prefix carry Ev = 0; give them lane 0's (valid, finite)
-                        // row so that 0*R is 0 and not 0*NaN from a row absent in the helper file
-                        int rowoff = rraw * WAVE;
-                        rowoff = bulk ? rowoff : __builtin_amdgcn_readlane(rowoff, 0);
-                        // lane 0 is the site nearest to the test sites: largest alpha of the pass.
-                        // Every factor of this pass lies in [1 - E0, 1 + E0*Rmax].
-                        const double e0 = readlane_f64(Ev, 0);
-                        const double om = 1.0 - e0, op = fma(e0, P.rmax, 1.0);
-                        const int lowbits = 1024 - ((__double2hiint(om) >> 20) & 0x7ff);
-                        const int hibits = ((__double2hiint(op) >> 20) & 0x7ff) - 1022;
-                        const int span8 = 8 * min(max(hibits, lowbits), 125);
                         int cnt_blk = cnt;                              // sites left to the block loops
                         if (MODE == 1) {
                             // FARSUM.  A site is FAR when alpha*|R| <= far_eps for every pair of the slice and every
@@ -595,8 +580,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             bool moml = false;
                             int pos = lane;
                             if (FARSUM && kmom) {
-                                const int slot = slot_tab[rraw];
-                                moml = bulk && slot < kmom && Ev * rowmax[rraw] <= P.far_eps && nfar_tot < FAR_CAP;
+                                const double ri = rowmax[rraw];                 // row's max |R|, its moment slot in the low byte
+                                const int slot = __double2loint(ri) & 0xff;
+                                const double xr = Ev * ri;
+                                moml = bulk && slot < kmom && xr <= P.far_eps && nfar_tot < FAR_CAP;
                                 const unsigned long long mm = __ballot(moml);
                                 const int nfar = __popcll(mm);
                                 if (nfar) {
@@ -604,18 +591,28 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                         // most sites carry the most frequent row (substitutions): its moments are kept in
                                         // MOM_COPIES copies so that one ds_add_f64 does not serialise ~45 lanes on one address
                                         double *mr = mom + (slot ? slot + MOM_COPIES - 1 : (lane & (MOM_COPIES - 1))) * FAR_ORDER;   // slot 0 = copies 0..C-1
-                                        const double E2 = Ev * Ev, E4 = E2 * E2, E3 = E2 * Ev;
+                                        // ds_add_f64 costs ~0.65 FMA slots per active lane (scripts/ubench_lds_atomic), so a
+                                        // lane only adds the powers it needs: x^k/k < 2e-15 is dropped (x = E * rowmax >= |F v|)
+                                        const double E2 = Ev * Ev;
                                         atomicAdd(mr, Ev);
                                         atomicAdd(mr + 1, E2);
-                                        atomicAdd(mr + 2, E3);
-                                        atomicAdd(mr + 3, E4);
-                                        if constexpr (FAR_ORDER >= 6) {
-                                            atomicAdd(mr + 4, E4 * Ev);
-                                            atomicAdd(mr + 5, E4 * E2);
-                                        }
-                                        if constexpr (FAR_ORDER >= 8) {
-                                            atomicAdd(mr + 6, E4 * E3);
-                                            atomicAdd(mr + 7, E4 * E4);
+                                        if (xr > 1.8e-5) {
+                                            const double E3 = E2 * Ev;
+                                            atomicAdd(mr + 2, E3);
+                                            if (xr > 3.0e-4) {
+                                                const double E4 = E2 * E2;
+                                                atomicAdd(mr + 3, E4);
+                                                if (FAR_ORDER >= 6 && xr > 1.6e-3) {
+                                                    atomicAdd(mr + 4, E4 * Ev);
+                                                    if (xr > 4.8e-3) {
+                                                        atomicAdd(mr + 5, E4 * E2);
+                                                        if (FAR_ORDER >= 8 && xr > 0.0105) {
+                                                            atomicAdd(mr + 6, E4 * E3);
+                                                            if (xr > 0.0189) atomicAdd(mr + 7, E4 * E4);
+                                                        }
+                                                    }
+                                                }
+                                            }
                                         }
                                     }
                                     const unsigned long long mn = mb & ~mm;
@@ -628,6 +625,18 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                     cnt_blk = cnt - nfar;
                                 }
                             }
+                            if (cnt_blk > 0) {                          // else every site of the pass went to the moments
+                            // lanes past the bulk prefix carry Ev = 0; give them lane 0's (valid, finite)
+                            // row so that 0*R is 0 and not 0*NaN from a row absent in the helper file
+                            int rowoff = rraw * WAVE;
+                            rowoff = bulk ? rowoff : __builtin_amdgcn_readlane(rowoff, 0);
+                            // lane 0 is the site nearest to the test sites: largest alpha of the pass.
+                            // Every factor of this pass lies in [1 - E0, 1 + E0*Rmax].
+                            const double e0 = readlane_f64(Ev, 0);
+                            const double om = 1.0 - e0, op = fma(e0, P.rmax, 1.0);
+                            const int lowbits = 1024 - ((__double2hiint(om) >> 20) & 0x7ff);
+                            const int hibits = ((__double2hiint(op) >> 20) & 0x7ff) - 1022;
+                            const int span8 = 8 * min(max(hibits, lowbits), 125);
                             scr[pos] = ScratchEnt{moml ? 0.0 : Ev, rowoff, 0};
                             __builtin_amdgcn_wave_barrier();
                             constexpr int BS = J >= 16 ? 4 : 8;        // sites per unrolled block
@@ -677,7 +686,15 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                 }
                             }
                             __builtin_amdgcn_wave_barrier();
+                            }
                         } else {
+                            int rowoff = rraw * WAVE;
+                            rowoff = bulk ? rowoff : __builtin_amdgcn_readlane(rowoff, 0);
+                            const double e0 = readlane_f64(Ev, 0);
+                            const double om = 1.0 - e0, op = fma(e0, P.rmax, 1.0);
+                            const int lowbits = 1024 - ((__double2hiint(om) >> 20) & 0x7ff);
+                            const int hibits = ((__double2hiint(op) >> 20) & 0x7ff) - 1022;
+                            const int span8 = 8 * min(max(hibits, lowbits), 125);
                             for (int l0 = 0; l0 < cnt; l0 += 8) {
                                 spend(span8);
 #pragma unroll
@@ -945,9 +962,9 @@ struct bmx_ctx {
     int32_t *d_sizes = nullptr, *d_row_off = nullptr;
     double *d_g = nullptr, *d_prop = nullptr, *d_x = nullptr, *d_abeta = nullptr, *d_A = nullptr;
     double *d_psel = nullptr, *d_R = nullptr, *d_Rt = nullptr, *d_rowmax = nullptr;
-    std::vector<double> h_A;
+    std::vector<double> h_A, h_rowmax;   // h_rowmax: [nslices][rows] max |R| (+inf: absent row)
     // far-field moment slots: the data's most frequent rows (set_sites)
-    uint8_t *d_slot_of_row = nullptr, *d_kmom = nullptr;
+    uint8_t *d_kmom = nullptr;
     int row_of_slot[MOM_SLOTS] = {0};
     uint64_t *d_patch_x = nullptr;
     double *d_patch_y = nullptr;
@@ -982,7 +999,7 @@ void free_model(bmx_ctx *c) {
     c->has_model = false;
 }
 void free_sites(bmx_ctx *c) {
-    dfree(c->d_genpos); dfree(c->d_row); dfree(c->d_row32); dfree(c->d_slot_of_row); dfree(c->d_kmom);
+    dfree(c->d_genpos); dfree(c->d_row); dfree(c->d_row32); dfree(c->d_kmom);
     c->has_sites = false;
 }
 void free_tests(bmx_ctx *c) {
@@ -1091,6 +1108,8 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_model(c);
+    free_sites(c);      // row indices and the moment slots belong to the model they were set under
+    free_tests(c);
     c->stat = m->stat; c->min_count = m->min_count; c->n_sizes = m->n_sizes;
     c->rows = m->row_off[m->n_sizes]; c->nx = m->nx; c->nab = m->nab; c->nA = nA;
     c->npairs = m->nx * m->nab;
@@ -1191,7 +1210,7 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
                 double &m = rm[(size_t)(p / WAVE) * c->rows + r];
                 m = (v != v) ? INFINITY : std::max(m, v);
             }
-        if ((rc = upload(c->d_rowmax, rm.data(), rm.size(), c->stream))) return rc;
+        c->h_rowmax.swap(rm);                 // uploaded by set_sites, with the rows' moment slots packed in
     }
     // per-site kernel: worst case per factor is max(span_hi, 54 bits for 1 - alpha) -- see the kernel
     c->renorm_every = std::max(1, std::min(16, 1000 / std::max(c->span_hi, 54)));
@@ -1254,7 +1273,17 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
             while (k < nslots && k < kcap && (double)cnt[(size_t)c->row_of_slot[k]] / (double)N * nfar * 23.0 > 30.0) k++;
             km[(size_t)a] = (uint8_t)k;
         }
-        if ((rc = upload(c->d_slot_of_row, (const uint8_t *)slot.data(), slot.size(), c->stream))) return rc;
+        // the kernel reads max |R| and the slot of a row with one load: the slot sits in the low mantissa
+        // byte of the (rounded up) maximum; +inf becomes NaN, which never compares as far
+        std::vector<double> packed(c->h_rowmax.size());
+        for (size_t k = 0; k < packed.size(); k++) {
+            uint64_t bits;
+            memcpy(&bits, &c->h_rowmax[k], sizeof bits);
+            bits = ((bits & ~0xffull) + 0x100ull) | slot[k % (size_t)c->rows];
+            memcpy(&packed[k], &bits, sizeof bits);
+        }
+        dfree(c->d_rowmax);
+        if ((rc = upload(c->d_rowmax, (const double *)packed.data(), packed.size(), c->stream))) return rc;
         if ((rc = upload(c->d_kmom, (const uint8_t *)km.data(), km.size(), c->stream))) return rc;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1320,12 +1349,12 @@ int bmx_ctx_scan(bmx_ctx *c) {
     P.center = c->d_center; P.center_hi = c->d_center_hi; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi; P.rmax = c->rmax;
     {
         // series cut at |x|^(order+1)/(order+1) <= ~6e-15 for the nearest far site
-        const double eps_default = FAR_ORDER >= 8 ? 0.03 : FAR_ORDER >= 6 ? 0.0115 : 0.002;
+        const double eps_default = FAR_ORDER >= 8 ? 0.0296 : FAR_ORDER >= 6 ? 0.0105 : 0.0016;
         double eps = getenv("BMX_FAR_EPS") ? atof(getenv("BMX_FAR_EPS")) : eps_default;   // accuracy experiments
         eps = std::min(std::max(eps, 0.0), 0.035);
         P.far_eps = eps;
         P.rowmax = c->d_rowmax;
-        P.slot_of_row = c->d_slot_of_row; P.kmom = c->d_kmom;
+        P.kmom = c->d_kmom;
         for (int k = 0; k < MOM_SLOTS; k++) P.row_of_slot[k] = c->row_of_slot[k];
         P.far_bits = (float)(eps * 1.4427 * 1.02);      // |log1p(x)| <= 1.02 |x| for |x| <= 0.035
     }
@@ -1335,7 +1364,7 @@ int bmx_ctx_scan(bmx_ctx *c) {
     // moment slots per wave: as many (64, 32, 16, 8, 0) as leave the R slice in LDS
     int mom_slots = MOM_SLOTS;
     auto lds_need = [&](int slots) {
-        return lds + (size_t)(c->rows + 2) * sizeof(double) + (size_t)(c->rows + 16) +
+        return lds + (size_t)(c->rows + 2) * sizeof(double) +
                (size_t)(SCAN_THREADS_MAX / WAVE) * (WAVE * sizeof(ScratchEnt) + (size_t)(slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double));
     };
     while (mom_slots >= 8 && lds_need(mom_slots) > (size_t)LDS_LIMIT_BYTES) mom_slots /= 2;
@@ -1384,8 +1413,8 @@ int bmx_ctx_scan(bmx_ctx *c) {
     // One wave per SIMD issues FP64 at half rate (measured), so a workgroup whose LDS footprint
     // allows only one resident workgroup per CU gets 8 waves instead of 4.
     int threads = SCAN_THREADS;
-    // grouped kernels: per-row max |R| and moment slots behind the slice, moments behind the scratch
-    const size_t lds_rm = (size_t)((c->rows + 1) & ~1) * sizeof(double) + (size_t)((c->rows + 15) & ~15);
+    // grouped kernels: per-row max |R| (+ moment slot) behind the slice, moments behind the scratch
+    const size_t lds_rm = (size_t)((c->rows + 1) & ~1) * sizeof(double);
     const size_t lds_wave = WAVE * sizeof(ScratchEnt) + (size_t)(mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double);
     size_t lds_bytes = (use_lds ? lds + (J ? lds_rm : 0) : 0) + (J ? (size_t)(threads / WAVE) * lds_wave : 0);
     if (J && 2 * lds_bytes > (size_t)LDS_LIMIT_BYTES) {
