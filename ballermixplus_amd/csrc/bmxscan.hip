@@ -711,7 +711,45 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     if (cnt < WAVE) break;
                     i = inx;
                 }
-                if (FARSUM && nfar_tot) {
+                // Ragged far end.  Beyond the zone common to all J windows, window j still holds n_j more sites.
+                // When those are far-field sites (alpha |R| <= 3e-4: the log1p series to third order is exact
+                // to 2e-15), the n_j grow along the order in which the windows end and all fit one pass, their
+                // power sums are simply carried on from test site to test site in the flush below:
+                // no generic passes at this end of the windows.
+                int nrag[J];
+                int nrmax = 0;
+                bool rag = false;
+                if (FARSUM && kmom) {
+                    const int ir = base + dir * lane;
+                    const bool inr = ir >= 0 && ir < N;
+                    const int ic = min(max(ir, 0), N - 1);
+                    const double g = P.genpos[ic];
+                    const int rr = (int)P.row[ic];
+                    // alpha = E F needs the site beyond ALL test sites of the group (not so when the group has no common zone)
+                    bool okr = __ballot(inr && (dir > 0 ? g < tnear : g > tnear)) == 0ull;
+#pragma unroll
+                    for (int w = 0; w < J; ++w) {
+                        const int j = dir > 0 ? w : J - 1 - w;           // the windows end in this order along the walk
+                        const double tq = readlane_f64(tj, j);
+                        const int wlo = __builtin_amdgcn_readlane(lo_j, j), whi = __builtin_amdgcn_readlane(hi_j, j);
+                        const bool in = inr && ir >= wlo && ir <= whi && (A * fabs(g - tq) <= P.zcut);
+                        const unsigned long long m = __ballot(in);
+                        const int nj = __popcll(m);
+                        okr = okr && (m & (m + 1ull)) == 0ull && nj >= nrmax;    // a prefix of the pass, growing with w
+                        nrag[j] = nj;
+                        nrmax = nj;
+                    }
+                    if (okr && nrmax > 0 && nrmax < WAVE) {
+                        const double Er = exp_neg(A * fabs(g - tnear));
+                        const bool far3 = lane >= nrmax || Er * rowmax[rr] <= 3e-4;     // NaN (absent row): false
+                        if (__ballot(far3) == ~0ull) {
+                            rag = true;
+                            scr[lane] = ScratchEnt{Er, rr * WAVE, 0};
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                }
+                if (FARSUM && (nfar_tot || rag)) {
                     // fold the moments: p_k = sum_rows M_k[row] R[row]^k, then acc_j *= exp(sum_k (-1)^(k+1) F_j^k p_k / k).
                     // |F v| <= far_eps = 0.03: the series is cut at |x|^9/9 < 2.2e-15 for the nearest far site
                     // and e^-9 of that per further unit of A*d.  |sum| <= nfar_tot * far_eps * 1.02 < 510.
@@ -719,6 +757,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     double p[FAR_ORDER];
 #pragma unroll
                     for (int k = 0; k < FAR_ORDER; ++k) p[k] = 0.0;
+                    if (nfar_tot) {
                     auto fold = [&](const double (&m)[FAR_ORDER], int slot) {
                         const double R = loadR(P.row_of_slot[slot] * WAVE);
                         const double R2 = R * R, R3 = R2 * R, R4 = R2 * R2;
@@ -774,18 +813,34 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
-                    spend(2 + (int)((float)nfar_tot * P.far_bits));
+                    }
+                    spend(2 + (int)((float)(nfar_tot + nrmax) * P.far_bits));
                     // t = p1 - f (p2/2 - f (p3/3 - ...)),  log product = f t
                     constexpr double inv[8] = {1.0, 0.5, 0.3333333333333333, 0.25, 0.2, 0.16666666666666666, 0.14285714285714285, 0.125};
 #pragma unroll
                     for (int k = 1; k < FAR_ORDER; ++k) p[k] *= inv[k];
+                    int l = 0;
 #pragma unroll
-                    for (int j = 0; j < J; ++j) {
+                    for (int w = 0; w < J; ++w) {
+                        const int j = dir > 0 ? w : J - 1 - w;
+                        if (rag) {
+                            for (; l < nrag[j]; ++l) {                    // the ragged sites that window j adds
+                                const ScratchEnt en = scr[l];
+                                const double v = en.e * loadR(en.ro), v2 = v * v;
+                                p[0] += v;
+                                p[1] = fma(v2, 0.5, p[1]);
+                                p[2] = fma(v2 * v, 0.3333333333333333, p[2]);
+                            }
+                        }
                         const double f = F[j];
                         double t = p[FAR_ORDER - 1];
 #pragma unroll
                         for (int k = FAR_ORDER - 2; k >= 0; --k) t = fma(-f, t, p[k]);
                         acc[j] *= exp_neg(-f * t);
+                    }
+                    if (rag) {
+                        __builtin_amdgcn_wave_barrier();
+                        base += dir * nrmax;
                     }
                 }
                 return base;
