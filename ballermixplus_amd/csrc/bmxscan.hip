@@ -543,6 +543,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
             };
 
             // bulk zone: sites i = base, base+dir, ... ; ok(i) is a prefix property along the walk
+            constexpr int ZONE_DONE = -0x7fffffff;
             auto bulk_zone = [&](int base, int dir, double tnear, double tfar) -> int {
                 double F[J];
                 {
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     }
                     if (rag) {
                         __builtin_amdgcn_wave_barrier();
-                        base += dir * nrmax;
+                        return ZONE_DONE;      // every window of the group has ended: nothing left on this side
                     }
                 }
                 return base;
@@ -850,10 +851,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
             for (int b = L_int; b < R_int; b += SP) generic_pass(b, +1, R_int);
             // right side
             int b = bulk_zone(R_int, +1, tL, t0);
-            while (!generic_pass(b, +1, N)) b += SP;
+            if (b != ZONE_DONE) while (!generic_pass(b, +1, N)) b += SP;
             // left side
             b = bulk_zone(L_int - 1, -1, t0, tL);
-            while (!generic_pass(b, -1, -1)) b -= SP;
+            if (b != ZONE_DONE) while (!generic_pass(b, -1, -1)) b -= SP;
 
             renorm_all();
 #pragma unroll
