@@ -70,7 +70,7 @@ constexpr int SCAN_THREADS_MAX = 512;         // 8 waves when one R slice fills 
 constexpr int LDS_LIMIT_BYTES = 160 * 1024;   // gfx950: 160 KiB per CU
 constexpr int MOM_SLOTS = 64;                 // grouped kernel: rows whose far-field sites are summed as moments
 #ifndef BMX_FAR_ORDER
-#define BMX_FAR_ORDER 6
+#define BMX_FAR_ORDER 8
 #endif
 constexpr int FAR_ORDER = BMX_FAR_ORDER;      // ... to this power of alpha*R (log1p series): 4, 6 or 8
 #ifndef BMX_MOM_COPIES
@@ -1430,10 +1430,11 @@ int bmx_ctx_scan(bmx_ctx *c) {
     // grouping pays when neighbouring test sites share most of their windows; a strided scan
     // (-s far larger than 1) is better served one test site per wave
     // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3
-    // (windows/s x1000 for J = 16 / 8 / 4 / per-site): stride 1: 1558/1214/910/264, 5: 1100/1044/864,
-    // 8: 908/956/825, 16: 614/784/737, 32: 395/584/620, 128: -/-/374/340 -> J by the median gap between
-    // test sites; beyond ~130 sites the per-site kernel takes over.
-    const int64_t gap_max = getenv("BMX_DENSE_GAP") ? atoll(getenv("BMX_DENSE_GAP")) : 128;
+    // (windows/s x1000 for J = 16 / 8 / 4 / per-site): stride 1: 2537/-/-/-, 2: 2221/1800, 3: 1899/1706,
+    // 4: 1540/1630/1124, 8: 1073/1299/1031, 16: 733/960/883, 32: 470/693/703, 64: 298/460/540,
+    // 128: 180/307/384/340, 160: -/-/335/338, 200: -/-/316/335 -> J by the median gap between test sites;
+    // beyond ~150 sites the per-site kernel takes over.
+    const int64_t gap_max = getenv("BMX_DENSE_GAP") ? atoll(getenv("BMX_DENSE_GAP")) : 150;
     const bool can_group = c->tests_sorted && c->test_gap <= gap_max && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
     int J = 0;
     // variants (A/B runs): 0 -> J by test-site gap, pairs near / quads mid / power sums far (default);
@@ -1442,7 +1443,8 @@ int bmx_ctx_scan(bmx_ctx *c) {
     if (can_group) {
         const int v = c->variant;
         J = (v == 0 || v == 5 || v == 8 || v == 10) ? 16 : (v == 3 || v == 6 || v == 9 || v == 11) ? 8 : (v == 4 || v == 7) ? 4 : 0;
-        if (v == 0) J = c->test_gap <= 6 ? 16 : c->test_gap <= 20 ? 8 : 4;
+        if (v == 0) J = c->test_gap <= 3 ? 16 : c->test_gap <= 28 ? 8 : 4;
+        if (v == 0 && getenv("BMX_FORCE_J")) J = atoi(getenv("BMX_FORCE_J"));   // threshold experiments: 16, 8 or 4
     }
     P.sites_per_block = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : 4);
     if (J == 16 && P.sites_per_block < 64) P.sites_per_block = 64;
