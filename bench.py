@@ -23,12 +23,16 @@ sys.path.insert(0, REPO)
 
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6300 achievable)
-# executed FP64 flop per evaluation (one site x one grid pair x one test site) in the default kernel.
-# 98 % of the bulk sites are in "far" passes and go four at a time:
-#   prod_m (1 + F v_m) = 1 + F(e1 + F(e2 + F(e3 + F e4))): 4 FMA + 1 MUL = 9 flop per test site per four sites,
-#   plus v_1..v_4 and e_1..e_4 (16 flop) shared by the J = 16 test sites of a group: 9/4 + 16/64 = 2.5
-# (near passes use pairs, 2.625; generic passes 3 -- both a few % of the sites).
-FLOP_PER_EVAL = 2.5
+# The scan kernel is bound by vector-instruction issue (every VALU instruction, FP64 or not, takes one
+# 4-cycle issue slot of its SIMD).  Its roofline figure prices every executed VALU wave-instruction as one
+# FP64 FMA (64 lanes x 2 flop) against the vector FP64 peak, i.e. it is the fraction of the chip's vector
+# issue slots the kernel fills.  The instruction count per unit of work is a PMC measurement
+# (SQ_INSTS_VALU over one launch, profiles/r01_pmc_scan_kernel_200k_windows.txt): 3.008e10 wave-instructions
+# for 1.899e12 evaluations (one site x one grid pair x one test site) = 1.014 per 64 evaluations on config 3.
+# (The exact product form alone needs >= 1.53: four sites per step, 4 FMA + 1 MUL per test site; the far field
+# -- 3/4 of the sites -- is summed as per-row moments of the log1p series and costs almost nothing per pair.)
+VALU_PER_64_EVALS = 1.014
+FLOP_PER_EVAL = VALU_PER_64_EVALS * 128 / 64
 SURVEY_FLOP_PER_EVAL = 32        # SURVEY.md 8(d) convention for the reference's FMA + log1p form
 
 
@@ -273,17 +277,21 @@ def _run():
                        'parallelism': 'test-site sharding, dp%d, RCCL all_gather of 16-B records per step' % world.size,
                        'checksum_clr_rank0': checksum},
             'roofline': {
-                'bound': 'valu_fp64', 'kernel': 'clr_scan_grouped_kernel<16,true,2>',
+                'bound': 'valu_fp64', 'kernel': 'clr_scan_grouped_kernel<16,true,3>',
                 'achieved': evals_s * FLOP_PER_EVAL / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': evals_s * FLOP_PER_EVAL / 1e12 / FP64_VALU_PEAK_TFLOPS, 'traffic': None,
                 'kernel_ms': k_ms, 'evals_per_launch': evals_per_step, 'evals_per_s': evals_s,
-                'flop_per_eval_executed': FLOP_PER_EVAL,
+                'valu_insts_per_64_evals': VALU_PER_64_EVALS,
+                'valu_calibration': 'SQ_INSTS_VALU, config 3, profiles/r01_pmc_scan_kernel_200k_windows.txt'
+                                    + ('' if args.config == 3 else ' (this workload is not calibrated separately)'),
                 'survey_convention_tflops': evals_s * SURVEY_FLOP_PER_EVAL / 1e12,
-                'note': 'lanes multiply (1+alpha*R) instead of summing log1p, four sites per step: 4 FMA + 1 MUL '
-                        'per test site per four sites; peak = vector FP64 (no contraction exists in this path, '
-                        'so not MFMA); survey_convention = SURVEY 8(d) "1 evaluation = 32 flop"'},
+                'note': 'achieved = executed VALU wave-instructions x 128 flop / kernel time: the share of the vector '
+                        'issue slots the kernel fills (peak = vector FP64; there is no contraction in this path, so '
+                        'not MFMA).  Algorithmic work: evals_per_s mixture-likelihood evaluations; under SURVEY 8(d) '
+                        '"1 evaluation = 32 flop" that is survey_convention_tflops, above the peak because near '
+                        'sites are multiplied four per step in product form and far sites are summed as moments'},
             'roofline_hbm': {
-                'bound': 'hbm', 'kernel': 'clr_scan_grouped_kernel<16,true,2>',
+                'bound': 'hbm', 'kernel': 'clr_scan_grouped_kernel<16,true,3>',
                 'achieved': bytes_per_step / (k_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': bytes_per_step / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                 'algorithmic_bytes_per_launch': bytes_per_step},

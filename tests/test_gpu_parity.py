@@ -254,6 +254,11 @@ def test_abi_error_paths():
         ctx.set_sites([0.1, 0.2], [1, 99])           # row outside the table
     with pytest.raises(_lib.BmxError):
         engine.Context(999)
+    # a new model invalidates the site arrays set under the old one (row numbering, moment slots)
+    ctx.set_sites([0.1, 0.2], [1, 2])
+    ctx.set_model(model, [100.0, 1000.0])
+    with pytest.raises(_lib.BmxError):
+        ctx.set_tests([0.1], [0], [1])
     ctx.close()
 
 
@@ -561,6 +566,54 @@ def test_partial_last_group_costs_nothing_extra():
         ctx.scan(); ctx.sync()
         per_window[step] = ctx.last_scan_ms() / len(idx)
     assert per_window[12] < 6 * per_window[1] and per_window[40] < 8 * per_window[1], per_window
+    ctx.close()
+
+
+@pytest.mark.parametrize('stat,nosub', [('B2', False), ('B0', True), ('B1', False)])
+def test_far_field_moments_against_exact_products(stat, nosub):
+    """The default kernel sums far-field sites (alpha*|R| <= 0.03) as per-row moments of the log1p
+    series to 8th order; variant 10 multiplies every factor 1 + alpha*R.  Same argmax and nSites on
+    every window, CLR equal to 1e-11 relative (bound in DESIGN.md: 2e-15 per site at the threshold),
+    for data with and without substitutions and for the two-row B_1 table; J = 16, 8 and 4."""
+    eng = _engine()
+    from ballermixplus_amd import synth
+    from ballermixplus_amd.hostmodel import Grids
+    N, n = 300000, 100
+    phys, gen, k, nn = synth.synth_chromosome(N, n, 3)
+    if nosub:
+        keep = k < n
+        gen, k, nn = gen[keep], k[keep], nn[keep]
+        N = len(gen)
+    if stat == 'B1':
+        k = (k < n).astype(np.int64)                    # 1 = polymorphic, 0 = substitution
+        cnt = {(int(a), n): float(np.mean(k == a)) for a in (0, 1)}
+        minc = 1
+    else:
+        cnt = {(a, b): f for a, b, f in synth.spect_from_counts(k, nn)}
+        minc = int(k.min())
+    grid = Grids(None, None, False, False, None, None)
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays(stat, minc, [n], cnt, {n: 1.0}, xs, ab)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, model.rows_of(k, nn))
+    for step, M in ((1, 4096), (7, 2048), (40, 1024)):
+        idx = (N // 3 + step * np.arange(M)).astype(np.int64)
+        lo, hi = np.zeros(M, np.int64), np.full(M, N - 1, np.int64)
+        out = {}
+        for variant in (10, 0):
+            ctx.set_variant(variant)
+            ctx.set_tests(gen[idx], lo, hi)
+            ctx.scan()
+            out[variant] = [a.copy() for a in ctx.fetch()]
+        same = np.ones(M, bool)
+        for f in (1, 2, 3):
+            same &= out[0][f] == out[10][f]
+        # the two-row B_1 table has grid points tied to rounding (see cases.compare_rows): there the two
+        # forms may pick different ends of a tie, with the same CLR
+        assert same.all() or (stat == 'B1' and same.mean() > 0.98), (stat, step, same.mean())
+        assert np.array_equal(out[0][4][same], out[10][4][same]), (stat, step)
+        assert np.allclose(out[0][0], out[10][0], rtol=1e-11, atol=1e-13), (stat, step)
     ctx.close()
 
 
