@@ -7,8 +7,8 @@
 //       locate_kernel / finalize_kernel: test-site positions, per-slice argmax merge + nSites
 //       surface_kernel           <- the full T[A,x,alpha] surface of one site (v1:449-450 wish)
 //
-// Environment knobs (diagnostics / A-B runs only): BMX_TRACE, BMX_LDS_PAD, BMX_DENSE_GAP; the scan
-// variant is chosen with bmx_ctx_set_variant().
+// Environment knobs (diagnostics / A-B runs only): BMX_TRACE, BMX_LDS_PAD, BMX_DENSE_GAP, BMX_FORCE_J,
+// BMX_FAR_EPS, BMX_MOM_SLOTS; the scan variant is chosen with bmx_ctx_set_variant().
 //
 // K2 formulation.  For a test site t and linkage value A the reference sums, over the sites
 // i of the window with alpha_i = exp(-A*|g_i - t|) >= 1e-8 and g_i != t (v1:454-457),
@@ -19,6 +19,9 @@
 // every few sites so it cannot over/underflow, and takes a single log per (t, A, pair).
 // Lanes run over the (x, alpha_beta) pairs, so nothing is reduced across lanes until the
 // final argmax; alpha_i and row_i are computed lanes-over-sites and broadcast.
+// Far from the test sites (alpha*|R| <= 0.03: three quarters of a window) not even that: the sites'
+// alpha^k are added to per-row moments and the product picks up exp(sum_k +-F^k/k sum_rows R^k M_k)
+// once per zone -- the log1p series to 8th order, cut below 2e-15 (see clr_scan_grouped_kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -106,9 +106,12 @@ typedef struct bmx_ctx bmx_ctx;
 
 int bmx_ctx_create(bmx_ctx **out, int device);
 void bmx_ctx_destroy(bmx_ctx *c);
-/* Build the selection table on the device (K1) and keep it resident. */
+/* Build the selection table on the device (K1) and keep it resident.  Call order: set_model, then
+ * set_sites, then set_tests; a new model discards the site and test arrays set under the old one (their
+ * row indices belong to it), and new sites discard nothing but must precede the next set_tests. */
 int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t nA);
-/* Copy the site arrays of one chromosome to the device. */
+/* Copy the site arrays of one chromosome to the device (and rank its rows by frequency for the scan
+ * kernel's far-field moments). */
 int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t *row);
 /* Copy test sites + window bounds to the device (and locate each test site). */
 int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64_t *win_lo,

@@ -4,7 +4,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
-        k = r['Kernel_Name'].split('(')[0][-60:]
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '')[:70]
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         disp[k].add(r['Dispatch_Id'])
 for k, d in agg.items():
