@@ -805,17 +805,17 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             if (m2[u][0].x == 0.0) continue;              // no far site of this row in the zone
-                            double2 *mp = reinterpret_cast<double2 *>(mom + (s0 + u + MOM_COPIES - 1) * FAR_ORDER);
                             double m[FAR_ORDER];
 #pragma unroll
                             for (int q = 0; q < FAR_ORDER / 2; ++q) {
                                 m[2 * q] = m2[u][q].x;
                                 m[2 * q + 1] = m2[u][q].y;
-                                mp[q] = double2{0.0, 0.0};               // ready for the next zone
                             }
                             fold(m, min(s0 + u, MOM_SLOTS - 1));
                         }
                     }
+                    // ready for the next zone: one lane-parallel sweep over the slots that may have been used
+                    for (int idx = MOM_COPIES * FAR_ORDER + lane; idx < (kmom + MOM_COPIES - 1) * FAR_ORDER; idx += WAVE) mom[idx] = 0.0;
                     __builtin_amdgcn_wave_barrier();
                     }
                     spend(2 + (int)((float)(nfar_tot + nrmax) * P.far_bits));
@@ -1295,6 +1295,7 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_sites(c);
+    free_tests(c);      // test sites were located in the old site array
     int rc;
     if ((rc = upload(c->d_genpos, genpos, (size_t)N, c->stream))) return rc;
     if (wide) {

@@ -108,7 +108,7 @@ int bmx_ctx_create(bmx_ctx **out, int device);
 void bmx_ctx_destroy(bmx_ctx *c);
 /* Build the selection table on the device (K1) and keep it resident.  Call order: set_model, then
  * set_sites, then set_tests; a new model discards the site and test arrays set under the old one (their
- * row indices belong to it), and new sites discard nothing but must precede the next set_tests. */
+ * row indices belong to it), and new sites discard the test sites (located in the old array). */
 int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t nA);
 /* Copy the site arrays of one chromosome to the device (and rank its rows by frequency for the scan
  * kernel's far-field moments). */

@@ -259,6 +259,13 @@ def test_abi_error_paths():
     ctx.set_model(model, [100.0, 1000.0])
     with pytest.raises(_lib.BmxError):
         ctx.set_tests([0.1], [0], [1])
+    # ... and new sites invalidate the test sites located in the old array
+    ctx.set_sites([0.1, 0.2, 0.3], [1, 2, 3])
+    ctx.set_tests([0.2], [0], [2])
+    ctx.scan()
+    ctx.set_sites([0.1, 0.2], [1, 2])
+    with pytest.raises(_lib.BmxError):
+        ctx.scan()
     ctx.close()
 
 
