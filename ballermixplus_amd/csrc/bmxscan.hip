@@ -71,7 +71,8 @@ constexpr int WAVE = 64;
 constexpr int SCAN_THREADS = 256;             // 4 waves per workgroup (default)
 constexpr int SCAN_THREADS_MAX = 512;         // 8 waves when one R slice fills most of a CU's LDS
 constexpr int LDS_LIMIT_BYTES = 160 * 1024;   // gfx950: 160 KiB per CU
-constexpr int MOM_SLOTS = 64;                 // grouped kernel: rows whose far-field sites are summed as moments
+constexpr int MOM_SLOTS = 254;                // grouped kernel: rows whose far-field sites can be summed as moments
+constexpr int MOM_SLOTS_LDS = 64;             // ... of which this many are used while the R slice occupies the LDS
 #ifndef BMX_FAR_ORDER
 #define BMX_FAR_ORDER 8
 #endif
@@ -1421,8 +1422,9 @@ int bmx_ctx_scan(bmx_ctx *c) {
     P.part_T = c->d_part_T; P.part_lin = c->d_part_lin; P.part_ns = c->d_part_ns;
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
     if (const char *pad = getenv("BMX_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
-    // moment slots per wave: as many (64, 32, 16, 8, 0) as leave the R slice in LDS
-    int mom_slots = MOM_SLOTS;
+    // moment slots per wave: as many (64, 32, 16, 8, 0) as leave the R slice in LDS; when the table is
+    // too large for LDS anyway (many sample sizes: the sites spread over many rows), all MOM_SLOTS
+    int mom_slots = MOM_SLOTS_LDS;
     auto lds_need = [&](int slots) {
         return lds + (size_t)(c->rows + 2) * sizeof(double) +
                (size_t)(SCAN_THREADS_MAX / WAVE) * (WAVE * sizeof(ScratchEnt) + (size_t)(slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double));
@@ -1430,6 +1432,7 @@ int bmx_ctx_scan(bmx_ctx *c) {
     while (mom_slots >= 8 && lds_need(mom_slots) > (size_t)LDS_LIMIT_BYTES) mom_slots /= 2;
     if (mom_slots < 8) mom_slots = 0;
     const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES;
+    if (!fits || c->variant == 1) mom_slots = MOM_SLOTS;
     P.mom_slots = mom_slots;
     // grouping pays when neighbouring test sites share most of their windows; a strided scan
     // (-s far larger than 1) is better served one test site per wave

@@ -576,12 +576,13 @@ def test_partial_last_group_costs_nothing_extra():
     ctx.close()
 
 
-@pytest.mark.parametrize('stat,nosub', [('B2', False), ('B0', True), ('B1', False)])
-def test_far_field_moments_against_exact_products(stat, nosub):
+@pytest.mark.parametrize('stat,nosub,spread', [('B2', False, 0), ('B0', True, 0), ('B1', False, 0), ('B2', False, 30)])
+def test_far_field_moments_against_exact_products(stat, nosub, spread):
     """The default kernel sums far-field sites (alpha*|R| <= 0.03) as per-row moments of the log1p
     series to 8th order; variant 10 multiplies every factor 1 + alpha*R.  Same argmax and nSites on
     every window, CLR equal to 1e-11 relative (bound in DESIGN.md: 2e-15 per site at the threshold),
-    for data with and without substitutions and for the two-row B_1 table; J = 16, 8 and 4."""
+    for data with and without substitutions, for the two-row B_1 table and for 31 sample sizes (a
+    table too large for LDS: R from L2, 254 moment slots); J = 16, 8 and 4."""
     eng = _engine()
     from ballermixplus_amd import synth
     from ballermixplus_amd.hostmodel import Grids
@@ -591,6 +592,13 @@ def test_far_field_moments_against_exact_products(stat, nosub):
         keep = k < n
         gen, k, nn = gen[keep], k[keep], nn[keep]
         N = len(gen)
+    sizes, props = [n], {n: 1.0}
+    if spread:                                          # missing data: sample sizes n-spread..n, counts rescaled
+        rng = np.random.default_rng(5)
+        n2 = rng.integers(n - spread, n + 1, N)
+        k = np.where(k == nn, n2, np.maximum(1, np.minimum(n2 - 1, (k * n2) // nn)))
+        nn = n2
+        sizes = sorted(set(nn.tolist()))
     if stat == 'B1':
         k = (k < n).astype(np.int64)                    # 1 = polymorphic, 0 = substitution
         cnt = {(int(a), n): float(np.mean(k == a)) for a in (0, 1)}
@@ -598,9 +606,11 @@ def test_far_field_moments_against_exact_products(stat, nosub):
     else:
         cnt = {(a, b): f for a, b, f in synth.spect_from_counts(k, nn)}
         minc = int(k.min())
+    if spread:
+        props = {int(s_): float(sum(f for (a, b), f in cnt.items() if b == s_)) for s_ in sizes}
     grid = Grids(None, None, False, False, None, None)
     xs, ab, As = grid.scan_order()
-    model = eng.ModelArrays(stat, minc, [n], cnt, {n: 1.0}, xs, ab)
+    model = eng.ModelArrays(stat, minc, sizes, cnt, props, xs, ab)
     ctx = eng.Context(0)
     ctx.set_model(model, As)
     ctx.set_sites(gen, model.rows_of(k, nn))
