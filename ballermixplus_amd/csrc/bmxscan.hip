@@ -224,6 +224,7 @@ struct ScanParams {
     const uint8_t *kmom;
     int row_of_slot[MOM_SLOTS];
     int mom_slots;     // slots per wave allocated in LDS (<= MOM_SLOTS)
+    unsigned long long *prof;   // -DBMX_PROFILE builds: cycles per kernel section, summed over waves (else unused)
     float far_bits;    // far_eps * log2(e): exponent-budget bits per far site
     int sites_per_block;
     double *part_T;    // [nslices][M]
@@ -409,8 +410,22 @@ struct alignas(16) ScratchEnt {
     int pad;
 };
 
+// -DBMX_PROFILE: s_memtime stamps between the sections of the grouped kernel (diagnostic builds only; the
+// stamps serialise outstanding LDS/scalar loads, so the split is approximate).  Sections: 0 sites between
+// the test sites, 1 zone set-up, 2 per-pass work, 3 products over the near list, 4 ragged-end masks,
+// 5 fold of the moments, 6 flush (exp per test site), 7 generic walks past the zones, 8 best-tracking per A.
+#ifdef BMX_PROFILE
+#define PROF_MARK(k) do { const long long now_ = clock64(); prof_[k] += now_ - tprev_; tprev_ = now_; } while (0)
+#else
+#define PROF_MARK(k) do { } while (0)
+#endif
+
 template <int J, bool USE_LDS, int MODE_>
 __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(ScanParams P) {
+#ifdef BMX_PROFILE
+    long long prof_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev_ = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then scratch
     constexpr int SP = WAVE / J;                                    // sites per generic pass
     constexpr bool QUAD = (MODE_ >= 2);                             // MODE_ 2 = MODE 1 + quads in far passes
@@ -561,6 +576,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                 double g_nx = P.genpos[min(max(i, 0), N - 1)];
                 int r_nx = (int)P.row[min(max(i, 0), N - 1)];
                 int nfar_tot = 0;                                  // far-field sites of this zone (FARSUM)
+                PROF_MARK(1);
                 while (true) {
                     const bool ok = dir > 0 ? (i <= hi_min) : (i >= lo_max);
                     const double g = g_nx;
@@ -630,6 +646,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                     cnt_blk = cnt - nfar;
                                 }
                             }
+                            PROF_MARK(2);
                             if (cnt_blk > 0) {                          // else every site of the pass went to the moments
                             // lanes past the bulk prefix carry Ev = 0; give them lane 0's (valid, finite)
                             // row so that 0*R is 0 and not 0*NaN from a row absent in the helper file
@@ -712,16 +729,18 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             }
                         }
                     }
+                    PROF_MARK(3);
                     base += dir * cnt;
                     if (cnt < WAVE) break;
                     i = inx;
                 }
+                PROF_MARK(2);
                 // Ragged far end.  Beyond the zone common to all J windows, window j still holds n_j more sites.
                 // When those are far-field sites (alpha |R| <= 3e-4: the log1p series to third order is exact
                 // to 2e-15), the n_j grow along the order in which the windows end and all fit one pass, their
                 // power sums are simply carried on from test site to test site in the flush below:
                 // no generic passes at this end of the windows.
-                int nrag[J];
+                int nrag_v = 0;                                    // lane: n_j of test site jl = lane % J
                 int nrmax = 0;
                 bool rag = false;
                 if (FARSUM && kmom) {
@@ -730,19 +749,34 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     const int ic = min(max(ir, 0), N - 1);
                     const double g = P.genpos[ic];
                     const int rr = (int)P.row[ic];
-                    // alpha = E F needs the site beyond ALL test sites of the group (not so when the group has no common zone)
-                    bool okr = __ballot(inr && (dir > 0 ? g < tnear : g > tnear)) == 0ull;
+                    // alpha = E F needs the sites beyond ALL test sites of the group (not so when the group has no
+                    // common zone), and the count below needs every window to be open already at `base`
+                    bool okr = __ballot(inr && (dir > 0 ? g < tnear : g > tnear)) == 0ull &&
+                               __ballot(dir > 0 ? lo_j > base : hi_j < base) == 0ull;
+                    if (okr) {
+                        // n_j = min(sites up to the window's index bound, sites with A*|g - t_j| <= zcut): the second
+                        // count is a bisection over the pass's positions (the predicate falls monotonically along
+                        // the walk: positions are sorted, FP subtraction and multiplication are monotone), done by
+                        // every lane for its own test site -- the same predicate, bit for bit, as the scan's
+                        scr_d[lane] = g;
+                        __builtin_amdgcn_wave_barrier();
+                        const int cnt1 = min(max(dir > 0 ? hi_j - base + 1 : base - lo_j + 1, 0), WAVE);
+                        int lo_n = 0, hi_n = WAVE;                 // predicate true below lo_n, false from hi_n on
 #pragma unroll
-                    for (int w = 0; w < J; ++w) {
-                        const int j = dir > 0 ? w : J - 1 - w;           // the windows end in this order along the walk
-                        const double tq = readlane_f64(tj, j);
-                        const int wlo = __builtin_amdgcn_readlane(lo_j, j), whi = __builtin_amdgcn_readlane(hi_j, j);
-                        const bool in = inr && ir >= wlo && ir <= whi && (A * fabs(g - tq) <= P.zcut);
-                        const unsigned long long m = __ballot(in);
-                        const int nj = __popcll(m);
-                        okr = okr && (m & (m + 1ull)) == 0ull && nj >= nrmax;    // a prefix of the pass, growing with w
-                        nrag[j] = nj;
-                        nrmax = nj;
+                        for (int it = 0; it < 7; ++it) {
+                            const int mid = min((lo_n + hi_n) >> 1, WAVE - 1);
+                            const bool pm = A * fabs(scr_d[mid] - tj) <= P.zcut;
+                            const bool act = lo_n < hi_n;
+                            lo_n = act && pm ? mid + 1 : lo_n;
+                            hi_n = act && !pm ? mid : hi_n;
+                        }
+                        nrag_v = min(cnt1, lo_n);
+                        __builtin_amdgcn_wave_barrier();
+                        // the windows must end in walk order (t ascending to the right, descending to the left)
+                        const int nb = dir > 0 ? __shfl_up(nrag_v, 1) : __shfl_down(nrag_v, 1);
+                        const bool edge = dir > 0 ? jl == 0 : jl == J - 1;
+                        okr = __ballot(!edge && nb > nrag_v) == 0ull;
+                        nrmax = __builtin_amdgcn_readlane(nrag_v, dir > 0 ? J - 1 : 0);
                     }
                     if (okr && nrmax > 0 && nrmax < WAVE) {
                         const double Er = exp_neg(A * fabs(g - tnear));
@@ -754,6 +788,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                         }
                     }
                 }
+                PROF_MARK(4);
                 if (FARSUM && (nfar_tot || rag)) {
                     // fold the moments: p_k = sum_rows M_k[row] R[row]^k, then acc_j *= exp(sum_k (-1)^(k+1) F_j^k p_k / k).
                     // |F v| <= far_eps = 0.03: the series is cut at |x|^9/9 < 2.2e-15 for the nearest far site
@@ -819,6 +854,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     for (int idx = MOM_COPIES * FAR_ORDER + lane; idx < (kmom + MOM_COPIES - 1) * FAR_ORDER; idx += WAVE) mom[idx] = 0.0;
                     __builtin_amdgcn_wave_barrier();
                     }
+                    PROF_MARK(5);
                     spend(2 + (int)((float)(nfar_tot + nrmax) * P.far_bits));
                     // t = p1 - f (p2/2 - f (p3/3 - ...)),  log product = f t
                     constexpr double inv[8] = {1.0, 0.5, 0.3333333333333333, 0.25, 0.2, 0.16666666666666666, 0.14285714285714285, 0.125};
@@ -829,7 +865,8 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     for (int w = 0; w < J; ++w) {
                         const int j = dir > 0 ? w : J - 1 - w;
                         if (rag) {
-                            for (; l < nrag[j]; ++l) {                    // the ragged sites that window j adds
+                            const int nj = __builtin_amdgcn_readlane(nrag_v, j);
+                            for (; l < nj; ++l) {                         // the ragged sites that window j adds
                                 const ScratchEnt en = scr[l];
                                 const double v = en.e * loadR(en.ro), v2 = v * v;
                                 p[0] += v;
@@ -843,6 +880,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                         for (int k = FAR_ORDER - 2; k >= 0; --k) t = fma(-f, t, p[k]);
                         acc[j] *= exp_neg(-f * t);
                     }
+                    PROF_MARK(6);
                     if (rag) {
                         __builtin_amdgcn_wave_barrier();
                         return ZONE_DONE;      // every window of the group has ended: nothing left on this side
@@ -852,13 +890,17 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
             };
 
             // sites between / at the test sites (and any part of the windows not covered by bulk)
+            PROF_MARK(8);
             for (int b = L_int; b < R_int; b += SP) generic_pass(b, +1, R_int);
+            PROF_MARK(0);
             // right side
             int b = bulk_zone(R_int, +1, tL, t0);
             if (b != ZONE_DONE) while (!generic_pass(b, +1, N)) b += SP;
+            PROF_MARK(7);
             // left side
             b = bulk_zone(L_int - 1, -1, t0, tL);
             if (b != ZONE_DONE) while (!generic_pass(b, -1, -1)) b -= SP;
+            PROF_MARK(7);
 
             renorm_all();
 #pragma unroll
@@ -890,6 +932,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
             }
         }
     }
+#ifdef BMX_PROFILE
+    if (lane == 0 && P.prof)
+        for (int k = 0; k < 9; ++k) atomicAdd(P.prof + k, (unsigned long long)prof_[k]);
+#endif
 }
 
 // Combine the per-slice winners of a test site; optionally recount nSites of the winning A
@@ -1025,6 +1071,7 @@ struct bmx_ctx {
     std::vector<double> h_A, h_rowmax;   // h_rowmax: [nslices][rows] max |R| (+inf: absent row)
     // far-field moment slots: the data's most frequent rows (set_sites)
     uint8_t *d_kmom = nullptr;
+    unsigned long long *d_prof = nullptr;   // -DBMX_PROFILE builds
     int row_of_slot[MOM_SLOTS] = {0};
     uint64_t *d_patch_x = nullptr;
     double *d_patch_y = nullptr;
@@ -1416,6 +1463,11 @@ int bmx_ctx_scan(bmx_ctx *c) {
         P.far_eps = eps;
         P.rowmax = c->d_rowmax;
         P.kmom = c->d_kmom;
+        P.prof = nullptr;
+#ifdef BMX_PROFILE
+        if (!c->d_prof) { HIP_TRY(hipMalloc((void **)&c->d_prof, 9 * sizeof(unsigned long long))); HIP_TRY(hipMemset(c->d_prof, 0, 9 * sizeof(unsigned long long))); }
+        P.prof = c->d_prof;
+#endif
         for (int k = 0; k < MOM_SLOTS; k++) P.row_of_slot[k] = c->row_of_slot[k];
         P.far_bits = (float)(eps * 1.4427 * 1.02);      // |log1p(x)| <= 1.02 |x| for |x| <= 0.035
     }
@@ -1512,6 +1564,18 @@ int bmx_ctx_sync(bmx_ctx *c) {
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+#ifdef BMX_PROFILE
+    if (c->d_prof) {
+        unsigned long long h[9];
+        HIP_TRY(hipMemcpy(h, c->d_prof, sizeof h, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(c->d_prof, 0, sizeof h));
+        double tot = 0;
+        for (int k = 0; k < 9; k++) tot += (double)h[k];
+        static const char *nm[9] = {"between test sites", "zone set-up", "per-pass work", "near-list products", "ragged-end masks",
+                                    "fold of moments", "flush", "generic walks past zones", "best-tracking"};
+        if (tot > 0) for (int k = 0; k < 9; k++) fprintf(stderr, "[bmx prof] %-26s %5.1f %%\n", nm[k], 100.0 * (double)h[k] / tot);
+    }
+#endif
     return BMX_OK;
 }
 
