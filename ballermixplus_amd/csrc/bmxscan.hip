@@ -749,9 +749,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     const int ic = min(max(ir, 0), N - 1);
                     const double g = P.genpos[ic];
                     const int rr = (int)P.row[ic];
-                    // alpha = E F needs the sites beyond ALL test sites of the group (not so when the group has no
-                    // common zone), and the count below needs every window to be open already at `base`
-                    bool okr = __ballot(inr && (dir > 0 ? g < tnear : g > tnear)) == 0ull &&
+                    // alpha = E F needs the sites strictly beyond ALL test sites of the group (not so when the group has
+                    // no common zone; a site AT a test position is not in that test site's window, v1:456), and the
+                    // count below needs every window to be open already at `base`
+                    bool okr = __ballot(inr && (dir > 0 ? g <= tnear : g >= tnear)) == 0ull &&
                                __ballot(dir > 0 ? lo_j > base : hi_j < base) == 0ull;
                     if (okr) {
                         // n_j = min(sites up to the window's index bound, sites with A*|g - t_j| <= zcut): the second
