@@ -668,13 +668,25 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             // e_k = elementary symmetric polynomials of v_1..v_4 shared by all J test sites:
                             // 4 FMA + 1 MUL per test site per four sites.
                             if (QUAD && lowbits <= 2) {
+                                // the R rows of the NEXT four sites are requested before this block's arithmetic, so the
+                                // two dependent LDS round trips (list entry -> row) of a block hide under the previous one
+                                double Rn[4], en_e[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const ScratchEnt en = scr[u];
+                                    en_e[u] = en.e;
+                                    Rn[u] = loadR(en.ro);
+                                }
                                 for (int l0 = 0; l0 < cnt_blk; l0 += 4) {
                                     spend(span8 / 2);
                                     double v[4];
 #pragma unroll
+                                    for (int u = 0; u < 4; ++u) v[u] = en_e[u] * Rn[u];
+#pragma unroll
                                     for (int u = 0; u < 4; ++u) {
-                                        const ScratchEnt en = scr[l0 + u];
-                                        v[u] = en.e * loadR(en.ro);
+                                        const ScratchEnt en = scr[min(l0 + 4 + u, WAVE - 1)];
+                                        en_e[u] = en.e;
+                                        Rn[u] = loadR(en.ro);
                                     }
                                     const double s01 = v[0] + v[1], q01 = v[0] * v[1];
                                     const double s23 = v[2] + v[3], q23 = v[2] * v[3];
