@@ -27,11 +27,11 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md (spec;
 # 4-cycle issue slot of its SIMD).  Its roofline figure prices every executed VALU wave-instruction as one
 # FP64 FMA (64 lanes x 2 flop) against the vector FP64 peak, i.e. it is the fraction of the chip's vector
 # issue slots the kernel fills.  The instruction count per unit of work is a PMC measurement
-# (SQ_INSTS_VALU over one launch, profiles/r01_pmc_scan_kernel_200k_windows.txt): 2.855e10 wave-instructions
-# for 1.899e12 evaluations (one site x one grid pair x one test site) = 0.962 per 64 evaluations on config 3.
+# (SQ_INSTS_VALU over one launch, profiles/r01_pmc_scan_kernel_200k_windows.txt): 2.889e10 wave-instructions
+# for 1.899e12 evaluations (one site x one grid pair x one test site) = 0.974 per 64 evaluations on config 3.
 # (The exact product form alone needs >= 1.53: four sites per step, 4 FMA + 1 MUL per test site; the far field
 # -- 3/4 of the sites -- is summed as per-row moments of the log1p series and costs almost nothing per pair.)
-VALU_PER_64_EVALS = 0.962
+VALU_PER_64_EVALS = 0.974
 FLOP_PER_EVAL = VALU_PER_64_EVALS * 128 / 64
 SURVEY_FLOP_PER_EVAL = 32        # SURVEY.md 8(d) convention for the reference's FMA + log1p form
 
