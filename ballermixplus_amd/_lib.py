@@ -29,6 +29,13 @@ class BmxModel(C.Structure):
     ]
 
 
+class BmxRecord(C.Structure):
+    """bmx_record: one result row as the multi-GPU gather moves it (16 bytes)."""
+    _fields_ = [('clr', C.c_double), ('lin', C.c_int32), ('nsites', C.c_int32)]
+
+
+RECORD_DTYPE = np.dtype([('clr', '<f8'), ('lin', '<i4'), ('nsites', '<i4')])
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _lp = C.POINTER(C.c_int64)
@@ -37,6 +44,7 @@ _vp = C.c_void_p
 # name -> (restype, argtypes); must list every symbol include/bmxscan.h declares
 PROTOTYPES = {
     'bmx_version': (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'bmx_build_id': (C.c_char_p, []),
     'bmx_last_error': (C.c_char_p, []),
     'bmx_device_count': (C.c_int, []),
     'bmx_alpha_cut': (C.c_double, []),
@@ -53,6 +61,10 @@ PROTOTYPES = {
     'bmx_ctx_last_scan_ms': (C.c_int, [_vp, _dp]),
     'bmx_ctx_fetch': (C.c_int, [_vp, _dp, _ip, _ip, _ip, _ip]),
     'bmx_ctx_result_ptrs': (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    'bmx_ctx_records': (C.c_int, [_vp, C.POINTER(_vp)]),
+    'bmx_ctx_fetch_records': (C.c_int, [_vp, _vp]),
+    'bmx_ctx_scan_write': (C.c_int, [_vp, C.c_char_p, _lp, _dp, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
+                                     C.c_char_p, C.c_int, C.c_int64]),
     'bmx_ctx_fetch_lut': (C.c_int, [_vp, _dp, _dp]),
     'bmx_ctx_set_variant': (C.c_int, [_vp, C.c_int]),
     'bmx_ctx_surface': (C.c_int, [_vp, C.c_double, C.c_int64, C.c_int64, _dp, _ip]),
@@ -64,10 +76,22 @@ PROTOTYPES = {
 }
 
 _lib = None
+SOURCES = ('csrc/bmxscan.hip', 'csrc/bmx_io.cpp', 'csrc/bmx_math.h', '../include/bmxscan.h')   # the Makefile's SRCS, in order
+
+
+def source_id():
+    """What bmx_build_id() of a library built from the sources in this tree returns."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in SOURCES:
+        with open(os.path.join(_HERE, rel), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def lib():
-    """Load libbmxscan.so once; raise if it is missing (no CPU fallback exists)."""
+    """Load libbmxscan.so once; raise if it is missing (no CPU fallback exists) or was built from other sources
+    than the ones next to it (a stale binary must not be tested or benchmarked silently)."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -78,6 +102,10 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        built, want = L.bmx_build_id().decode(), source_id()
+        if built != want and os.environ.get('BMX_ALLOW_STALE') != '1':
+            raise ImportError('%s is stale: built from sources %s, the tree has %s. Run `make -C %s`.'
+                              % (LIB_PATH, built, want, os.path.join(_HERE, 'csrc')))
         _lib = L
     return _lib
 

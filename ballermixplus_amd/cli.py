@@ -3,9 +3,11 @@
 InputData -> NeutralSFS -> get_neut_probs -> Grids -> NormalizedBetaBinom -> Scan (v1:777-799).
 
 Additions (do not change any reference command line):
-  --device K        GPU index for a single-process run (default 0, or LOCAL_RANK under torchrun)
+  --device K        GPU index for a single-process run (default 0)
 Multi-GPU: launch under `python -m torch.distributed.run --nproc-per-node N -m ballermixplus_amd.cli ...`;
-test sites are sharded over the ranks, rank 0 gathers (RCCL) and writes the output file.
+test sites are sharded over the ranks (rank r computes on GPU LOCAL_RANK), rank 0 gathers the 16-byte records
+(one RCCL gather) and writes the output file.  BMX_DIST_BACKEND=gloo BMX_SINGLE_DEVICE=1 lets several ranks
+share GPU 0 with a CPU gather: a rehearsal of the multi-rank control flow on a 1-GPU box.
 """
 import argparse
 import os
@@ -14,30 +16,52 @@ from datetime import datetime
 
 
 def build_parser():
-    parser = argparse.ArgumentParser()
-    parser.add_argument('-i', '--input', dest='infile', help='Path and name of your input file.\n', required=True)
-    parser.add_argument('-o', '--output', dest='outfile', help='Path and name of your output file.\n')
-    parser.add_argument('--spect', dest='spectfile', help='Path and name of the allele frequency spectrum file or configuration file.\n', required=True)
-    parser.add_argument('--minCount', dest='minCount', default=1, help='If rare variants are removed from the input, please provide the smallest allele count included in the input. Default value is 1.')
-    parser.add_argument('--getSpect', dest='getSpec', action='store_true', default=False, help='Option to generate frequency spectrum file from the concatenated input file. Use "-i" and "--spect" commands to provide names and paths to input and output files, respectively. Indicate the input type with "--MAF".\n')
-    parser.add_argument('--getConfig', dest='getConfig', action='store_true', default=False, help='Option to generate configuration file from the concatenated input file. Use "-i" and "--spect" commands to provide names and paths to input and output files, respectively.\n\n')
-    parser.add_argument('--findBal', dest='bal', action='store_true', default=False, help="Option to only look for footprints of balancing selection.\n")
-    parser.add_argument('--findPos', dest='pos', action='store_true', default=False, help="Option to only look for footprints of positive selection.\n")
-    parser.add_argument('--noFreq', dest='nofreq', action='store_true', default=False, help='Option to compute B_1 statistic and ignore allele frequency information (if given). All polymorphic sites (non-zero counts) will be considered as equivalent. Substitutions should be represented as having zero count in the input.')
-    parser.add_argument('--noSub', dest='nosub', action='store_true', default=False, help='Option to not include substitution in input data. B_0 or B_0maf will be computed.')
-    parser.add_argument('--MAF', dest='MAF', action='store_true', default=False, help='Option to compute B_2maf statistic and use minor allele frequency instead of polarized allele frequency (if given). The latter is default (B_2 statisitc).')
-    parser.add_argument('--usePhysPos', action='store_true', dest='phys', default=False, help='Option to use physical positions instead of genetic positions (in cM). Default is using genetic positions.\n')
-    parser.add_argument('--rec', dest='Rrate', default=1e-6, type=float, help='The uniform recombination rate in cM/nt. Default value is 1e-6 cM/nt. Only useful when choose to use physical positions as coordinates.\n\n')
-    parser.add_argument('--fixWinSize', action='store_true', dest='size', default=False, help='Option to fix the size (in nt) of sliding windows during scan. When true, please also provide the length of window in neucleotide (nt) with "-w" or "--window" command.\n')
-    parser.add_argument('-w', '--window', dest='w', type=int, default=0, help='Number of sites flanking the test locus on either side. When choose to fix window size ("--fixSize"), input the length of window in bp.\n')
-    parser.add_argument('--noCenter', action='store_true', dest='noCenter', default=False, help='Option to have the scanning windows not centered on informative sites. Require that the window size ("-w") in physical positions ("--usePhysPos") is provided. Default is True.\n')
-    parser.add_argument('-s', '--step', dest='step', type=float, default=1, help='Step size in bp (when using "--noCenter") or the number of informative sites. Default value is one site or one nucleotide.\n\n')
-    parser.add_argument('--fixX', dest='x', help='Option to fix the presumed equilibrium frequency.\n')
-    parser.add_argument('--fixAlpha', dest='abeta', type=float, default=None, help='Option to fix the alpha parameter in the beta-binomial distribution.\n')
-    parser.add_argument('--rangeA', dest='seqA', help='Range of the values of the linkage parameter A to optimize over. Format should follow <Amin>,<Amax>,<Astep> with no space around commas.\n')
-    parser.add_argument('--listA', dest='listA', help='Manually provide a list of A values to optimize over. Please separate the values with comma, no space.\n')
+    """Flags, destinations, types and defaults are the reference's (v1:718-753): its command lines run unchanged.
+    The help texts are this build's own wording."""
+    parser = argparse.ArgumentParser(description='BalLeRMix+ B-statistic scan on AMD Instinct MI355X (libbmxscan).')
+    parser.add_argument('-i', '--input', dest='infile', required=True,
+                        help='input file: header line, then tab-separated physPos, genPos, derived (or minor) allele count x, sample size n')
+    parser.add_argument('-o', '--output', dest='outfile', help='output file (7 tab-separated columns, one row per test site)')
+    parser.add_argument('--spect', dest='spectfile', required=True,
+                        help='neutral helper file to read: frequency spectrum (k n fraction) or, with --noFreq, the '
+                             'substitution/polymorphism configuration. With --getSpect / --getConfig: the file to WRITE')
+    parser.add_argument('--minCount', dest='minCount', default=1,
+                        help='smallest allele count present in the input when rare variants were filtered out (default 1; '
+                             'used as given only by the B_1 statistic, otherwise taken from the data)')
+    parser.add_argument('--getSpect', dest='getSpec', action='store_true', default=False,
+                        help='helper step: tabulate the (k, n) frequency spectrum of the concatenated input -i into --spect and exit (combine with --MAF / --noSub as for the scan)')
+    parser.add_argument('--getConfig', dest='getConfig', action='store_true', default=False,
+                        help='helper step: tabulate the substitution : polymorphism proportions per sample size of -i into --spect and exit')
+    parser.add_argument('--findBal', dest='bal', action='store_true', default=False,
+                        help='restrict the (x, alpha) grid to shapes typical of balancing selection')
+    parser.add_argument('--findPos', dest='pos', action='store_true', default=False,
+                        help='restrict the (x, alpha) grid to shapes typical of positive selection (ignored when --findBal is given, as in the reference)')
+    parser.add_argument('--noFreq', dest='nofreq', action='store_true', default=False,
+                        help='B_1: ignore allele frequencies; a site is a substitution (count 0) or a polymorphism (any other count)')
+    parser.add_argument('--noSub', dest='nosub', action='store_true', default=False,
+                        help='B_0 / B_0,MAF: the input holds polymorphic sites only, no substitutions')
+    parser.add_argument('--MAF', dest='MAF', action='store_true', default=False,
+                        help='B_2,MAF / B_0,MAF: fold counts to minor-allele counts (default: polarised counts, B_2)')
+    parser.add_argument('--usePhysPos', action='store_true', dest='phys', default=False,
+                        help='measure distances on physical positions times --rec instead of on the genPos column')
+    parser.add_argument('--rec', dest='Rrate', default=1e-6, type=float,
+                        help='uniform recombination rate in cM per nucleotide for --usePhysPos (default 1e-6)')
+    parser.add_argument('--fixWinSize', action='store_true', dest='size', default=False,
+                        help='windows of a fixed physical length; give the length in nucleotides with -w')
+    parser.add_argument('-w', '--window', dest='w', type=int, default=0,
+                        help='number of informative sites on either side of the test site, or with --fixWinSize the window length in nucleotides (default 0: every site with alpha >= 1e-8)')
+    parser.add_argument('--noCenter', action='store_true', dest='noCenter', default=False,
+                        help='with --fixWinSize: test positions every -s nucleotides instead of at informative sites')
+    parser.add_argument('-s', '--step', dest='step', type=float, default=1,
+                        help='test every s-th informative site, or every s nucleotides with --noCenter (default 1)')
+    parser.add_argument('--fixX', dest='x', help='fix the equilibrium frequency x instead of searching the x grid')
+    parser.add_argument('--fixAlpha', dest='abeta', type=float, default=None,
+                        help='fix the beta-binomial alpha parameter instead of searching the alpha grid')
+    parser.add_argument('--rangeA', dest='seqA', help='linkage parameter grid as <Amin>,<Amax>,<Astep> (no spaces)')
+    parser.add_argument('--listA', dest='listA', help='linkage parameter grid as a comma-separated list (no spaces)')
     # additions
-    parser.add_argument('--device', dest='device', type=int, default=None, help='GPU index (MI355X build only).')
+    parser.add_argument('--device', dest='device', type=int, default=None,
+                        help='GPU index for a single-process run (MI355X build only; not allowed under torch.distributed.run, where every rank uses GPU LOCAL_RANK)')
     return parser
 
 
@@ -65,8 +89,12 @@ def main(argv=None):
     from .hostmodel import Grids, InputData, NeutralSFS
     from .scan import Scan
 
-    world = distributed.World.from_env()
-    device = opt.device if opt.device is not None else world.local_rank
+    world = distributed.World.from_env(backend=os.environ.get('BMX_DIST_BACKEND'))
+    if world.distributed and opt.device is not None:
+        # torch tensors of the gather and the scan context must live on the same GPU: one rank, one GPU
+        print('--device cannot be combined with a multi-process launch: each rank uses GPU LOCAL_RANK.')
+        sys.exit(1)
+    device = opt.device if opt.device is not None else world.device_index
     verbose = world.rank == 0
 
     def say(*a):
@@ -84,10 +112,10 @@ def main(argv=None):
     say('\n \t alpha= ' + ', '.join([str(a) for a in grid.abeta]))
     say('\n \t A= ' + ', '.join([str(A) for A in grid.A]))
     Sel_Probs = engine.NormalizedBetaBinom(data, grid, opt.nofreq, opt.MAF, opt.nosub, device=device)
-    say(("\n%s. Start computing likelihood raito..." % (datetime.now())))
+    say(("\n%s. Start computing likelihood ratios..." % (datetime.now())))
     runner = world.sharded_runner() if world.distributed else None
     Scan(data, Neutral, Sel_Probs, grid, opt.outfile if world.rank == 0 else None, fixSize=opt.size, r=opt.w,
-         s=opt.step, phys=opt.phys, noCenter=opt.noCenter, runner=runner)
+         s=opt.step, phys=opt.phys, noCenter=opt.noCenter, runner=runner, verbose=verbose)
     world.finish()
     say(f'\n{datetime.now()}. Pipeline finished.')
 

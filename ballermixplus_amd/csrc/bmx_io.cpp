@@ -13,6 +13,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
 #include <string>
 
@@ -74,55 +75,116 @@ int bmx_input_count(const char *path, int64_t *n_out) {
 }
 
 // Parse N data lines into caller-allocated arrays.  coord = column pos_col (0 physical, 1 genetic).
+// The data bytes are cut into one range per thread at line boundaries: a counting pass gives every range its
+// first row index, a second pass parses.  Anything this strict reader does not recognise (a field that does not
+// start with a digit, sign or '.', hex floats, inf/nan, trailing junk) is reported as malformed, and the caller's
+// Python reader then reproduces the reference's own behaviour (and error) for that file.
+}  // extern "C"
+
+#include <thread>
+#include <vector>
+
+namespace {
+inline bool num_start(char c) { return (c >= '0' && c <= '9') || c == '+' || c == '-' || c == '.'; }
+inline bool float_chars(const char *a, const char *b) {
+    for (; a < b; ++a) {
+        const char c = *a;
+        if (!((c >= '0' && c <= '9') || c == '+' || c == '-' || c == '.' || c == 'e' || c == 'E')) return false;
+    }
+    return true;
+}
+
+// one '\n'-terminated line; false = malformed
+inline bool parse_line(const char *line, int pos_col, int64_t &phys, double &coord, int64_t &k, int64_t &n) {
+    char *q;
+    const char *f0 = line;
+    while (*f0 == ' ') ++f0;                       // the reference strips the line
+    if (!num_start(*f0)) return false;
+    const double c0 = strtod(f0, &q);
+    if (q == f0 || *q != '\t' || !float_chars(f0, q)) return false;
+    const char *f1 = q + 1;
+    if (!num_start(*f1)) return false;
+    const double c1 = strtod(f1, &q);
+    if (q == f1 || *q != '\t' || !float_chars(f1, q)) return false;
+    const char *f2 = q + 1;
+    if (!num_start(*f2) || *f2 == '.') return false;
+    const long long kk = strtoll(f2, &q, 10);
+    if (q == f2 || *q != '\t') return false;
+    const char *f3 = q + 1;
+    if (!num_start(*f3) || *f3 == '.') return false;      // an empty last column must not swallow the next line
+    const long long nn = strtoll(f3, &q, 10);
+    if (q == f3) return false;
+    while (*q == ' ' || *q == '\r') ++q;
+    if (*q != '\n' && *q != '\t') return false;
+    phys = (int64_t)c0;                            // int(float(col0)): truncation toward zero
+    coord = pos_col == 0 ? c0 : c1;
+    k = kk;
+    n = nn;
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
 int bmx_input_parse(const char *path, int64_t N, int pos_col, int64_t *phys, double *coord, int64_t *k, int64_t *n) {
     if (!path || !phys || !coord || !k || !n || (pos_col != 0 && pos_col != 1)) { bmx_set_error_("bad argument"); return BMX_E_INVALID; }
     Mapped m;
     int rc = map_file(path, m);
     if (rc) return rc;
-    // strtod/strtoll need a terminator: copy the last line if the file does not end in '\n'
-    std::string tail;
     const char *s = m.p, *end = m.p + m.n;
-    if (s < end) s = next_line(s, end);
-    int64_t i = 0;
-    while (s < end && i < N) {
-        const char *e = next_line(s, end);
-        const char *line = s;
-        if (e == end && (e == s || e[-1] != '\n')) {   // unterminated last line
-            if (blank(s, e)) break;
-            tail.assign(s, e);
-            tail.push_back('\n');
-            line = tail.c_str();
-        }
-        char *q;
-        const char *f0 = line;
-        while (*f0 == ' ') ++f0;
-        double c0 = strtod(f0, &q);
-        if (q == f0 || *q != '\t') goto bad;
-        {
-            const char *f1 = q + 1;
-            double c1 = strtod(f1, &q);
-            if (q == f1 || *q != '\t') goto bad;
-            const char *f2 = q + 1;
-            long long kk = strtoll(f2, &q, 10);
-            if (q == f2 || *q != '\t') goto bad;
-            const char *f3 = q + 1;
-            long long nn = strtoll(f3, &q, 10);
-            if (q == f3) goto bad;
-            while (*q == ' ' || *q == '\r') ++q;
-            if (*q != '\n' && *q != '\t') goto bad;
-            phys[i] = (int64_t)c0;            // int(float(col0)): truncation toward zero
-            coord[i] = pos_col == 0 ? c0 : c1;
-            k[i] = kk;
-            n[i] = nn;
-        }
-        ++i;
-        s = e;
-        continue;
-    bad:
-        bmx_set_error_(("malformed input at data line " + std::to_string((long long)i + 1)).c_str());
+    if (s < end) s = next_line(s, end);            // header
+    // strtod/strtoll need a terminator: an unterminated last line is parsed from a copy
+    const char *body_end = end;
+    std::string tail;
+    if (s < end && end[-1] != '\n') {
+        const char *last = end;
+        while (last > s && last[-1] != '\n') --last;
+        body_end = last;
+        if (!blank(last, end)) { tail.assign(last, end); tail.push_back('\n'); }
+    }
+    if (tail.empty() && body_end > s) {            // like bmx_input_count: one blank last line is not data
+        const char *last = body_end - 1;
+        while (last > s && last[-1] != '\n') --last;
+        if (blank(last, body_end)) body_end = last;
+    }
+    const size_t bytes = (size_t)(body_end - s);
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 32), bytes / (1 << 20) + 1);
+    std::vector<const char *> cut((size_t)T + 1);
+    cut[0] = s;
+    for (int t = 1; t < T; ++t) {
+        const char *c = s + bytes * (size_t)t / (size_t)T;
+        cut[(size_t)t] = c <= cut[(size_t)t - 1] ? cut[(size_t)t - 1] : next_line(c - 1, body_end);   // start of the line after the cut byte
+    }
+    cut[(size_t)T] = body_end;
+    std::vector<int64_t> first((size_t)T + 1, 0), bad((size_t)T, -1);
+    auto for_ranges = [&](auto fn) {
+        if (T == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(fn, t);
+        for (auto &x : th) x.join();
+    };
+    for_ranges([&](int t) {
+        int64_t c = 0;
+        for (const char *a = cut[(size_t)t]; a < cut[(size_t)t + 1]; a = next_line(a, cut[(size_t)t + 1])) c++;
+        first[(size_t)t + 1] = c;
+    });
+    for (int t = 0; t < T; ++t) first[(size_t)t + 1] += first[(size_t)t];
+    const int64_t total = first[(size_t)T] + (tail.empty() ? 0 : 1);
+    if (total != N) { bmx_set_error_(total < N ? "fewer data lines than announced" : "more data lines than announced"); return BMX_E_INVALID; }
+    for_ranges([&](int t) {
+        int64_t i = first[(size_t)t];
+        for (const char *a = cut[(size_t)t]; a < cut[(size_t)t + 1]; a = next_line(a, cut[(size_t)t + 1]), ++i)
+            if (!parse_line(a, pos_col, phys[i], coord[i], k[i], n[i])) { bad[(size_t)t] = i; return; }
+    });
+    int64_t first_bad = -1;
+    for (int t = 0; t < T; ++t)
+        if (bad[(size_t)t] >= 0 && (first_bad < 0 || bad[(size_t)t] < first_bad)) first_bad = bad[(size_t)t];
+    if (first_bad < 0 && !tail.empty() && !parse_line(tail.c_str(), pos_col, phys[N - 1], coord[N - 1], k[N - 1], n[N - 1])) first_bad = N - 1;
+    if (first_bad >= 0) {
+        bmx_set_error_(("malformed input at data line " + std::to_string((long long)first_bad + 1)).c_str());
         return BMX_E_INVALID;
     }
-    if (i != N) { bmx_set_error_("fewer data lines than announced"); return BMX_E_INVALID; }
     return BMX_OK;
 }
 
@@ -186,6 +248,105 @@ char *py_repr(char *out, double v) {
 }
 }  // namespace
 
+// The grids' printed forms (Python's str of the grid objects, made by the caller), split once.
+struct bmx_row_tables_ {
+    std::vector<std::pair<const char *, int>> tx, ta, tA;
+    std::string store;
+};
+
+extern "C" bmx_row_tables_ *bmx_row_tables_new_(const char *xs, int nx, const char *abs_, int nab, const char *As, int nA) {
+    bmx_row_tables_ *t = new bmx_row_tables_();
+    size_t total = 0;
+    auto measure = [&](const char *s, int n) { for (int i = 0; i < n; ++i) { size_t l = strlen(s) + 1; total += l; s += l; } };
+    measure(xs, nx); measure(abs_, nab); measure(As, nA);
+    t->store.reserve(total);
+    auto take = [&](const char *s, int n, std::vector<std::pair<const char *, int>> &v) {
+        for (int i = 0; i < n; ++i) {
+            const int len = (int)strlen(s);
+            const size_t at = t->store.size();
+            t->store.append(s, (size_t)len + 1);
+            v.push_back({(const char *)at, len});          // offsets first: the string may not move after reserve, but stay safe
+            s += len + 1;
+        }
+    };
+    take(xs, nx, t->tx); take(abs_, nab, t->ta); take(As, nA, t->tA);
+    for (auto *v : {&t->tx, &t->ta, &t->tA})
+        for (auto &e : *v) e.first = t->store.data() + (size_t)e.first;
+    return t;
+}
+extern "C" void bmx_row_tables_free_(bmx_row_tables_ *t) { delete t; }
+
+namespace {
+// rows [b, e) into out; false on a grid index outside the tables
+bool format_rows(std::vector<char> &out, const bmx_row_tables_ *t, int64_t b, int64_t e, const int64_t *phys, const double *gen,
+                 const double *clr, const int32_t *ix, const int32_t *ia, const int32_t *iA, const int32_t *lin, const int32_t *nsites) {
+    const int nx = (int)t->tx.size(), nab = (int)t->ta.size(), nA = (int)t->tA.size();
+    out.resize((size_t)(e - b) * 96 + 512);
+    size_t used = 0;
+    for (int64_t r = b; r < e; ++r) {
+        if (used + 512 > out.size()) out.resize(out.size() * 3 / 2 + 512);
+        char *o = out.data() + used;
+        o += sprintf(o, "%lld\t", (long long)phys[r]);
+        o = py_repr(o, gen[r]);
+        int a, bb, d;
+        if (lin) {
+            const int32_t L = lin[r];
+            d = L < 0 ? -1 : L / (nx * nab);
+            const int32_t p = L < 0 ? 0 : L % (nx * nab);
+            a = p / nab;
+            bb = p % nab;
+        } else {
+            a = ix[r]; bb = ia[r]; d = iA[r];
+        }
+        if (d < 0) {
+            memcpy(o, "\t0.0\t0.0\t0.0\t0.0\t0.0\n", 21);
+            o += 21;
+        } else {
+            if (a < 0 || a >= nx || bb < 0 || bb >= nab || d >= nA) return false;
+            *o++ = '\t';
+            o = py_repr(o, clr[r]);
+            *o++ = '\t';
+            memcpy(o, t->tx[(size_t)a].first, (size_t)t->tx[(size_t)a].second); o += t->tx[(size_t)a].second;
+            *o++ = '\t';
+            memcpy(o, t->ta[(size_t)bb].first, (size_t)t->ta[(size_t)bb].second); o += t->ta[(size_t)bb].second;
+            *o++ = '\t';
+            memcpy(o, t->tA[(size_t)d].first, (size_t)t->tA[(size_t)d].second); o += t->tA[(size_t)d].second;
+            o += sprintf(o, "\t%d\n", nsites[r]);
+        }
+        used = (size_t)(o - out.data());
+    }
+    out.resize(used);
+    return true;
+}
+}  // namespace
+
+// n rows to f: formatted on several threads (Python-repr-exact floats are the cost of a million-row file), written in order
+extern "C" int bmx_write_chunk_(FILE *f, const bmx_row_tables_ *t, int64_t n, const int64_t *phys, const double *gen, const double *clr,
+                                const int32_t *ix, const int32_t *ia, const int32_t *iA, const int32_t *lin, const int32_t *nsites) {
+    if (n <= 0) return BMX_OK;
+    unsigned hw = std::thread::hardware_concurrency();
+    const int T = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, 16), n / 8192 + 1);
+    std::vector<std::vector<char>> bufs((size_t)T);
+    std::vector<char> okv((size_t)T, 1);
+    auto work = [&](int k) {
+        okv[(size_t)k] = format_rows(bufs[(size_t)k], t, n * k / T, n * (k + 1) / T, phys, gen, clr, ix, ia, iA, lin, nsites) ? 1 : 0;
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < T; ++k) th.emplace_back(work, k);
+        for (auto &x : th) x.join();
+    }
+    for (int k = 0; k < T; ++k)
+        if (!okv[(size_t)k]) { bmx_set_error_("grid index out of range"); return BMX_E_INVALID; }
+    for (int k = 0; k < T; ++k)
+        if (!bufs[(size_t)k].empty() && fwrite(bufs[(size_t)k].data(), 1, bufs[(size_t)k].size(), f) != bufs[(size_t)k].size()) {
+            bmx_set_error_("write failed");
+            return BMX_E_INVALID;
+        }
+    return BMX_OK;
+}
+
 extern "C" {
 
 // repr(v) into buf (>= 32 bytes); returns its length.  Exposed for the tests.
@@ -204,48 +365,17 @@ int bmx_write_rows(const char *path, int64_t M, const int64_t *phys, const doubl
         bmx_set_error_("bad argument");
         return BMX_E_INVALID;
     }
-    auto split = [](const char *s, int n, std::vector<std::pair<const char *, int>> &v) {
-        for (int i = 0; i < n; ++i) {
-            int len = (int)strlen(s);
-            v.push_back({s, len});
-            s += len + 1;
-        }
-    };
-    std::vector<std::pair<const char *, int>> tx, ta, tA;
-    split(xs, nx, tx); split(abs_, nab, ta); split(As, nA, tA);
     FILE *f = fopen(path, "a");
     if (!f) { bmx_set_error_((std::string("cannot open ") + path + ": " + strerror(errno)).c_str()); return BMX_E_INVALID; }
-    std::vector<char> buf(1 << 20);
-    size_t used = 0;
-    for (int64_t t = 0; t < M; ++t) {
-        if (used + 512 > buf.size()) { fwrite(buf.data(), 1, used, f); used = 0; }
-        char *o = buf.data() + used;
-        o += sprintf(o, "%lld\t", (long long)phys[t]);
-        o = py_repr(o, gen[t]);
-        if (iA[t] < 0) {
-            memcpy(o, "\t0.0\t0.0\t0.0\t0.0\t0.0\n", 21);
-            o += 21;
-        } else {
-            if (ix[t] < 0 || ix[t] >= nx || ia[t] < 0 || ia[t] >= nab || iA[t] >= nA) {
-                fclose(f);
-                bmx_set_error_("grid index out of range");
-                return BMX_E_INVALID;
-            }
-            *o++ = '\t';
-            o = py_repr(o, clr[t]);
-            *o++ = '\t';
-            memcpy(o, tx[ix[t]].first, tx[ix[t]].second); o += tx[ix[t]].second;
-            *o++ = '\t';
-            memcpy(o, ta[ia[t]].first, ta[ia[t]].second); o += ta[ia[t]].second;
-            *o++ = '\t';
-            memcpy(o, tA[iA[t]].first, tA[iA[t]].second); o += tA[iA[t]].second;
-            o += sprintf(o, "\t%d\n", nsites[t]);
-        }
-        used = (size_t)(o - buf.data());
+    bmx_row_tables_ *t = bmx_row_tables_new_(xs, nx, abs_, nab, As, nA);
+    int rc = BMX_OK;
+    for (int64_t off = 0; off < M && !rc; off += 1 << 18) {      // bounded formatting buffers
+        const int64_t cnt = std::min<int64_t>(1 << 18, M - off);
+        rc = bmx_write_chunk_(f, t, cnt, phys + off, gen + off, clr + off, ix + off, ia + off, iA + off, nullptr, nsites + off);
     }
-    if (used) fwrite(buf.data(), 1, used, f);
-    if (fclose(f) != 0) { bmx_set_error_("write failed"); return BMX_E_INVALID; }
-    return BMX_OK;
+    bmx_row_tables_free_(t);
+    if (fclose(f) != 0 && !rc) { bmx_set_error_("write failed"); rc = BMX_E_INVALID; }
+    return rc;
 }
 
 }  // extern "C"

@@ -7,8 +7,9 @@
 //       locate_kernel / finalize_kernel: test-site positions, per-slice argmax merge + nSites
 //       surface_kernel           <- the full T[A,x,alpha] surface of one site (v1:449-450 wish)
 //
-// Environment knobs (diagnostics / A-B runs only): BMX_TRACE, BMX_LDS_PAD, BMX_DENSE_GAP, BMX_FORCE_J,
-// BMX_FAR_EPS, BMX_MOM_SLOTS; the scan variant is chosen with bmx_ctx_set_variant().
+// The shipped library reads ONE environment variable, BMX_TRACE (stage messages on stderr, no effect on results).
+// Tuning knobs for A/B runs (BMX_LDS_PAD, BMX_DENSE_GAP, BMX_FORCE_J, BMX_FAR_EPS, BMX_MOM_SLOTS, BMX_SPB) exist only
+// in the diagnostic builds (-DBMX_DIAG: `make diag|prof|count`); the scan variant is chosen with bmx_ctx_set_variant().
 //
 // K2 formulation.  For a test site t and linkage value A the reference sums, over the sites
 // i of the window with alpha_i = exp(-A*|g_i - t|) >= 1e-8 and g_i != t (v1:454-457),
@@ -28,8 +29,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <errno.h>
+
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -53,6 +57,16 @@ int fail(int code, const std::string &msg) {
     } while (0)
 
 // BMX_TRACE=1 in the environment prints one line per stage to stderr (diagnostics only)
+// tuning knobs: environment variables in diagnostic builds, always absent in the shipped library
+const char *diag_env(const char *name) {
+#ifdef BMX_DIAG
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 bool trace_on() {
     static int on = -1;
     if (on < 0) on = getenv("BMX_TRACE") ? 1 : 0;
@@ -81,8 +95,23 @@ constexpr int FAR_ORDER = BMX_FAR_ORDER;      // ... to this power of alpha*R (l
 #define BMX_MOM_COPIES 8
 #endif
 constexpr int MOM_COPIES = BMX_MOM_COPIES;                 // copies of the most frequent row's moments (lane % 8): fewer LDS conflicts
-constexpr int FAR_CAP = 16384;                // ... at most this many sites per zone (exponent budget)
+#ifndef BMX_FOLD_BATCH
+#define BMX_FOLD_BATCH 4
+#endif
+constexpr int MID_CAP = 32;                   // grouped kernel: sites between the test sites of a group staged in LDS (12 B each)
+constexpr int FAR_CAP = 8192;                 // ... at most this many sites per zone (exponent budget: 8192 * 0.05 * 1.49 bits < 1000)
 constexpr double LN2 = 0.693147180559945309417232121458;
+// Far field: log1p(x) = sum_k (-1)^(k+1) w_k x^k.  To 8th order the w_k are the Taylor coefficients 1/k economised on
+// [-0.05, 0.05] (Taylor polynomial of degree 24 re-expanded in Chebyshev polynomials of x/0.05, cut after T_8, constant
+// term -1.9e-17 dropped): max error 8.9e-16 on the whole interval, against 2.3e-13 for the plain Taylor cut -- Taylor's
+// accuracy at |x| <= 0.0296 with the far field starting 0.5 units of A*d nearer to the test sites.  Lanes that drop
+// high orders (x^k/k < 2e-15) see w_k - 1/k only as |w_1 - 1| |x| + |w_2 - 1/2| x^2 + ... < 1e-17.  Lower orders: Taylor.
+#if BMX_FAR_ORDER >= 8
+__device__ constexpr double FAR_W[8] = {0.9999999999998467, 0.4999999999996164, 0.3333333341509627, 0.25000000122701976,
+                                        0.19999882322703955, 0.16666529319200146, 0.1434841013671569, 0.12562715480255862};
+#else
+__device__ constexpr double FAR_W[8] = {1.0, 0.5, 0.3333333333333333, 0.25, 0.2, 0.16666666666666666, 0.14285714285714285, 0.125};
+#endif
 
 // ----------------------------------------------------------------------------- K1
 struct LutParams {
@@ -242,22 +271,32 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // r = -z - n*ln2 (two-term), degree-13 Taylor polynomial (|r| <= 0.347: truncation 4e-18), ldexp.
 // ~19 instructions instead of ~34; about 1 ulp, which is all alpha needs (alpha only feeds
 // log-likelihood terms; the window PREDICATE never goes through this function).
+// p*r + c with the constant c in a scalar register pair.  gfx950 VALU instructions take no 64-bit literals, and left to
+// itself the compiler keeps every polynomial coefficient of exp_neg (called from five places) in a VGPR pair for the whole
+// kernel -- 20 VGPRs of a 256-VGPR budget -- and spends a v_mov_b64 per Horner step because it selects the two-address
+// v_fmac, which overwrites its addend.  The "s" constraint makes the coefficient two s_mov_b32 (scalar issue slots,
+// rematerialised wherever needed) and the step one three-address v_fma_f64.
+__device__ __forceinline__ double fma_sc(double p, double r, double c) {
+    double o;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "s"(c));
+    return o;
+}
+
 __device__ __forceinline__ double exp_neg(double z) {
     const double t = -z;
     const double n = rint(t * 1.4426950408889634);
     double r = fma(-n, 0.6931471805599453, t);
     r = fma(-n, 2.3190468138462996e-17, r);
-    double p = 1.6059043836821613e-10;            // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);          // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);         // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);         // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);        // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);          // 1/8!
-    p = fma(p, r, 0.0001984126984126984);         // 1/7!
-    p = fma(p, r, 0.001388888888888889);          // 1/6!
-    p = fma(p, r, 0.008333333333333333);          // 1/5!
-    p = fma(p, r, 0.041666666666666664);          // 1/4!
-    p = fma(p, r, 0.16666666666666666);           // 1/3!
+    double p = fma_sc(1.6059043836821613e-10, r, 2.08767569878681e-09);   // 1/13!, 1/12!
+    p = fma_sc(p, r, 2.505210838544172e-08);         // 1/11!
+    p = fma_sc(p, r, 2.755731922398589e-07);         // 1/10!
+    p = fma_sc(p, r, 2.7557319223985893e-06);        // 1/9!
+    p = fma_sc(p, r, 2.48015873015873e-05);          // 1/8!
+    p = fma_sc(p, r, 0.0001984126984126984);         // 1/7!
+    p = fma_sc(p, r, 0.001388888888888889);          // 1/6!
+    p = fma_sc(p, r, 0.008333333333333333);          // 1/5!
+    p = fma_sc(p, r, 0.041666666666666664);          // 1/4!
+    p = fma_sc(p, r, 0.16666666666666666);           // 1/3!
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -277,7 +316,7 @@ template <bool USE_LDS>
 __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_kernel(ScanParams P) {
     extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS
     const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform: group-level scalars live in SGPRs
     const int slice = blockIdx.x % P.nslices;   // blocks b, b+8 share an XCD: one R slice per L2
     const int64_t chunk = blockIdx.x / P.nslices;
     const int p = slice * WAVE + lane;
@@ -419,12 +458,21 @@ struct alignas(16) ScratchEnt {
 #else
 #define PROF_MARK(k) do { } while (0)
 #endif
+// -DBMX_COUNT: event counters (wave-uniform adds; no stamps), summed over waves into P.prof[16..31]
+#ifdef BMX_COUNT
+#define CNT(k, n) do { cnt_[k] += (unsigned long long)(n); } while (0)
+#else
+#define CNT(k, n) do { } while (0)
+#endif
 
 template <int J, bool USE_LDS, int MODE_>
 __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(ScanParams P) {
 #ifdef BMX_PROFILE
-    long long prof_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev_ = clock64();
+#endif
+#ifdef BMX_COUNT
+    unsigned long long cnt_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then scratch
     constexpr int SP = WAVE / J;                                    // sites per generic pass
@@ -432,7 +480,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
     constexpr bool FARSUM = (MODE_ == 3);                           // MODE_ 3 = MODE 2 + far-field moments
     constexpr int MODE = MODE_ ? 1 : 0;
     const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform: group-level scalars live in SGPRs
     const int slice = blockIdx.x % P.nslices;
     const int64_t chunk = blockIdx.x / P.nslices;
     const int p = slice * WAVE + lane;
@@ -459,6 +507,9 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
     ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_tail) + wave * WAVE;
     const int mom_len = (P.mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER;   // slot 0 in MOM_COPIES copies, slots 1.., 3 spare
     double *mom = lds_tail + (blockDim.x / WAVE) * WAVE * 2 + wave * mom_len;
+    // ... and the sites between the group's test sites (position, row * 64): read by the generic passes of all nA iterations
+    double *mid_g = lds_tail + (blockDim.x / WAVE) * (WAVE * 2 + mom_len) + wave * (MID_CAP + MID_CAP / 2);
+    int *mid_ro = reinterpret_cast<int *>(mid_g + MID_CAP);
     if (MODE_ == 3) {
         for (int idx = lane; idx < mom_len; idx += WAVE) mom[idx] = 0.0;
         __builtin_amdgcn_wave_barrier();
@@ -486,6 +537,13 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
         }
         int L_int = min(c0, hi_min + 1), R_int = max(cU, lo_max);
         if (hi_min < lo_max) { L_int = c0; R_int = c0; hi_min = -1; lo_max = N; }   // no bulk zone
+        // the sites between the test sites are visited once per A: keep them in LDS (global latency once per group)
+        const bool staged = R_int - L_int <= MID_CAP;
+        if (staged && lane < R_int - L_int) {
+            mid_g[lane] = P.genpos[L_int + lane];
+            mid_ro[lane] = (int)P.row[L_int + lane] * WAVE;
+        }
+        __builtin_amdgcn_wave_barrier();
 
         // running best per test site: key = (clamped exponent + 2^17) << 13 | iA  (iA = 8191: none yet)
         double acc[J], bestM[J];
@@ -514,11 +572,40 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
             };
             const int span_generic = max(P.span_hi, 54);     // alpha < 1  =>  1 - alpha >= 2^-53
 
+            // SP sites x J test sites with per-(site, test site) alpha (lane = site slot * J + test site): acc_j *= 1 + alpha R
+            auto apply_pass = [&](double alpha, int rowoff, unsigned long long m_in, double *buf) {
+                if (MODE == 1) {
+                    buf[lane] = alpha;
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int s = 0; s < SP; ++s) {
+                    if (((m_in >> (s * J)) & ((1ull << J) - 1ull)) == 0ull) continue;
+                    const double R = loadR(__builtin_amdgcn_readlane(rowoff, s * J));
+                    if (MODE == 1) {
+                        const double2 *a2 = reinterpret_cast<const double2 *>(buf + s * J);
+#pragma unroll
+                        for (int j = 0; j < J; j += 2) {
+                            const double2 a = a2[j >> 1];              // uniform address: LDS broadcast
+                            acc[j] *= fma(a.x, R, 1.0);
+                            acc[j + 1] *= fma(a.y, R, 1.0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) acc[j] *= fma(readlane_f64(alpha, s * J + j), R, 1.0);
+                    }
+                }
+                if (MODE == 1) __builtin_amdgcn_wave_barrier();
+            };
+
             // one generic pass over SP sites starting at b, stepping dir; returns "all finished"
-            auto generic_pass = [&](int b, int dir, int lim) -> bool {
+            auto generic_pass = [&](int b, int dir, int lim, bool from_lds) -> bool {
                 const int i = b + dir * sl;
                 const bool inr = dir > 0 ? (i < lim) : (i > lim);
-                const double g = inr ? P.genpos[i] : 0.0;
+                // both loads up front: the row is needed only when some site is in a window, but waiting for
+                // the ballot would put two global round trips in series
+                const double g = !inr ? 0.0 : from_lds ? mid_g[i - L_int] : P.genpos[i];
+                const int rowoff = !inr ? 0 : from_lds ? mid_ro[i - L_int] : (int)P.row[i] * WAVE;
                 const bool inwin = inr && i >= lo_j && i <= hi_j;
                 const double z = A * fabs(g - tj);
                 const bool in = inwin && (z <= P.zcut) && (g != tj);
@@ -529,34 +616,14 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                  (dir > 0 ? (!inr || i > hi_j || (i >= lo_j && g > tj && z > P.zcut))
                                           : (!inr || i < lo_j || (i <= hi_j && g < tj && z > P.zcut)));
                 const unsigned long long m_in = __ballot(in);
+                CNT(7, 1);
                 if (m_in != 0ull) {
+                    CNT(6, 1);
                     const double alpha = in ? exp_neg(z) : 0.0;
-                    const int rowoff = inr ? (int)P.row[i] * WAVE : 0;
                     // factors of this pass lie in [1 - a_max, 1 + a_max*Rmax]; away from the test sites
                     // (every alpha <= 1/2) that is [1/2, 2^span_hi], not the 54-bit worst case
                     spend(SP * (__ballot(in && z < 0.6931471805599453) == 0ull ? max(P.span_hi, 2) : span_generic));
-                    if (MODE == 1) {
-                        scr_d[lane] = alpha;
-                        __builtin_amdgcn_wave_barrier();
-                    }
-#pragma unroll
-                    for (int s = 0; s < SP; ++s) {
-                        if (((m_in >> (s * J)) & ((1ull << J) - 1ull)) == 0ull) continue;
-                        const double R = loadR(__builtin_amdgcn_readlane(rowoff, s * J));
-                        if (MODE == 1) {
-                            const double2 *a2 = reinterpret_cast<const double2 *>(scr_d + s * J);
-#pragma unroll
-                            for (int j = 0; j < J; j += 2) {
-                                const double2 a = a2[j >> 1];              // uniform address: LDS broadcast
-                                acc[j] *= fma(a.x, R, 1.0);
-                                acc[j + 1] *= fma(a.y, R, 1.0);
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < J; ++j) acc[j] *= fma(readlane_f64(alpha, s * J + j), R, 1.0);
-                        }
-                    }
-                    if (MODE == 1) __builtin_amdgcn_wave_barrier();
+                    apply_pass(alpha, rowoff, m_in, scr_d);
                 }
                 return __ballot(fin) == ~0ull;
             };
@@ -587,7 +654,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     const bool bulk = ok && (A * fabs(g - tfar) <= P.zcut);
                     const unsigned long long mb = __ballot(bulk);
                     const int cnt = __popcll(mb);
+                    CNT(13, 1);
                     if (cnt) {
+                        CNT(0, 1);
+                        CNT(14, cnt);
                         const double Ev = bulk ? exp_neg(A * fabs(g - tnear)) : 0.0;
                         int cnt_blk = cnt;                              // sites left to the block loops
                         if (MODE == 1) {
@@ -607,6 +677,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                 moml = bulk && slot < kmom && xr <= P.far_eps && nfar_tot < FAR_CAP;
                                 const unsigned long long mm = __ballot(moml);
                                 const int nfar = __popcll(mm);
+                                PROF_MARK(10);
                                 if (nfar) {
                                     if (moml) {
                                         // most sites carry the most frequent row (substitutions): its moments are kept in
@@ -636,6 +707,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                             }
                                         }
                                     }
+                                    PROF_MARK(11);
                                     const unsigned long long mn = mb & ~mm;
                                     auto rank = [&](unsigned long long m) {
                                         return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -644,10 +716,13 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                     pos = moml ? cnt - nfar + rank(mm) : bulk ? rank(mn) : lane;
                                     nfar_tot += nfar;
                                     cnt_blk = cnt - nfar;
+                                    CNT(5, nfar);
                                 }
                             }
                             PROF_MARK(2);
                             if (cnt_blk > 0) {                          // else every site of the pass went to the moments
+                            CNT(1, 1);
+                            CNT(4, cnt_blk);
                             // lanes past the bulk prefix carry Ev = 0; give them lane 0's (valid, finite)
                             // row so that 0*R is 0 and not 0*NaN from a row absent in the helper file
                             int rowoff = rraw * WAVE;
@@ -662,23 +737,29 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             scr[pos] = ScratchEnt{moml ? 0.0 : Ev, rowoff, 0};
                             __builtin_amdgcn_wave_barrier();
                             constexpr int BS = J >= 16 ? 4 : 8;        // sites per unrolled block
-                            // Far passes (every alpha <= 1/2: factors >= 1/2, the expanded product is well
-                            // conditioned) can take FOUR sites per step:
+                            // Sites with alpha <= 1/2 (factors >= 1/2: the expanded product is well conditioned) are
+                            // taken FOUR per step:
                             //   prod_m (1 + F v_m) = 1 + F e1 + F^2 e2 + F^3 e3 + F^4 e4   (Horner in F),
                             // e_k = elementary symmetric polynomials of v_1..v_4 shared by all J test sites:
-                            // 4 FMA + 1 MUL per test site per four sites.
-                            if (QUAD && lowbits <= 2) {
+                            // 4 FMA + 1 MUL per test site per four sites.  The near list is ordered by distance, so the
+                            // entries with E > 1/2 are a prefix: they go two per step (below), rounded up to whole blocks.
+                            const int npair = !QUAD ? cnt_blk
+                                                    : min(cnt_blk, (__popcll(__ballot(bulk && !moml && Ev > 0.5)) + BS - 1) & ~(BS - 1));
+                            const int span8q = 8 * min(max(hibits, 2), 125);
+                            PROF_MARK(9);
+                            if (QUAD && npair < cnt_blk) {
                                 // the R rows of the NEXT four sites are requested before this block's arithmetic, so the
                                 // two dependent LDS round trips (list entry -> row) of a block hide under the previous one
                                 double Rn[4], en_e[4];
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
-                                    const ScratchEnt en = scr[u];
+                                    const ScratchEnt en = scr[min(npair + u, WAVE - 1)];
                                     en_e[u] = en.e;
                                     Rn[u] = loadR(en.ro);
                                 }
-                                for (int l0 = 0; l0 < cnt_blk; l0 += 4) {
-                                    spend(span8 / 2);
+                                for (int l0 = npair; l0 < cnt_blk; l0 += 4) {
+                                    CNT(2, 1);
+                                    spend(span8q / 2);
                                     double v[4];
 #pragma unroll
                                     for (int u = 0; u < 4; ++u) v[u] = en_e[u] * Rn[u];
@@ -703,8 +784,9 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                         if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 8 chains in flight
                                     }
                                 }
-                            } else
-                            for (int l0 = 0; l0 < cnt_blk; l0 += BS) {
+                            }
+                            for (int l0 = 0; l0 < npair; l0 += BS) {
+                                CNT(3, 1);
                                 spend(span8 * BS / 8);
                                 double v[BS];
 #pragma unroll
@@ -802,10 +884,13 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     }
                 }
                 PROF_MARK(4);
+                CNT(15, 1);
                 if (FARSUM && (nfar_tot || rag)) {
+                    CNT(8, 1);
+                    CNT(11, rag ? 1 : 0);
                     // fold the moments: p_k = sum_rows M_k[row] R[row]^k, then acc_j *= exp(sum_k (-1)^(k+1) F_j^k p_k / k).
-                    // |F v| <= far_eps = 0.03: the series is cut at |x|^9/9 < 2.2e-15 for the nearest far site
-                    // and e^-9 of that per further unit of A*d.  |sum| <= nfar_tot * far_eps * 1.02 < 510.
+                    // |F v| <= far_eps = 0.05: 8th-order series with economised coefficients (see the flush), error < 9e-16 per
+                    // site.  |sum| <= nfar_tot * far_eps * 1.03 < 422.
                     __builtin_amdgcn_wave_barrier();
                     double p[FAR_ORDER];
 #pragma unroll
@@ -843,17 +928,20 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                         if (m[0] != 0.0) fold(m, 0);
                     }
                     // the other slots, four at a time: all LDS reads of a batch are in flight together
-                    for (int s0 = 1; s0 < kmom; s0 += 4) {
-                        double2 m2[4][FAR_ORDER / 2];
+                    CNT(10, kmom);
+                    constexpr int FB = BMX_FOLD_BATCH;                       // slots per batch: their LDS reads are in flight together
+                    for (int s0 = 1; s0 < kmom; s0 += FB) {
+                        double2 m2[FB][FAR_ORDER / 2];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < FB; ++u) {
                             double2 *mp = reinterpret_cast<double2 *>(mom + (s0 + u + MOM_COPIES - 1) * FAR_ORDER);
 #pragma unroll
                             for (int q = 0; q < FAR_ORDER / 2; ++q) m2[u][q] = mp[q];    // uniform address: LDS broadcast
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < FB; ++u) {
                             if (m2[u][0].x == 0.0) continue;              // no far site of this row in the zone
+                            CNT(9, 1);
                             double m[FAR_ORDER];
 #pragma unroll
                             for (int q = 0; q < FAR_ORDER / 2; ++q) {
@@ -870,9 +958,9 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     PROF_MARK(5);
                     spend(2 + (int)((float)(nfar_tot + nrmax) * P.far_bits));
                     // t = p1 - f (p2/2 - f (p3/3 - ...)),  log product = f t
-                    constexpr double inv[8] = {1.0, 0.5, 0.3333333333333333, 0.25, 0.2, 0.16666666666666666, 0.14285714285714285, 0.125};
+                    // t = w1 p1 - f (w2 p2 - f (w3 p3 - ...)),  log product = f t   (w_k: FAR_W above)
 #pragma unroll
-                    for (int k = 1; k < FAR_ORDER; ++k) p[k] *= inv[k];
+                    for (int k = 0; k < FAR_ORDER; ++k) p[k] *= FAR_W[k];
                     int l = 0;
 #pragma unroll
                     for (int w = 0; w < J; ++w) {
@@ -904,15 +992,15 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 
             // sites between / at the test sites (and any part of the windows not covered by bulk)
             PROF_MARK(8);
-            for (int b = L_int; b < R_int; b += SP) generic_pass(b, +1, R_int);
+            for (int b = L_int; b < R_int; b += SP) generic_pass(b, +1, R_int, staged);
             PROF_MARK(0);
             // right side
             int b = bulk_zone(R_int, +1, tL, t0);
-            if (b != ZONE_DONE) while (!generic_pass(b, +1, N)) b += SP;
+            if (b != ZONE_DONE) { CNT(12, 1); while (!generic_pass(b, +1, N, false)) { b += SP; CNT(12, 1); } }
             PROF_MARK(7);
             // left side
             b = bulk_zone(L_int - 1, -1, t0, tL);
-            if (b != ZONE_DONE) while (!generic_pass(b, -1, -1)) b -= SP;
+            if (b != ZONE_DONE) { CNT(12, 1); while (!generic_pass(b, -1, -1, false)) { b -= SP; CNT(12, 1); } }
             PROF_MARK(7);
 
             renorm_all();
@@ -928,26 +1016,34 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
             }
         }
 #pragma unroll
+        // slice winner per test site: (exponent, mantissa) compared exactly, ties to the smaller linear index; the one
+        // logarithm per test site is taken by finalize_kernel (no log, and none of its constants, in this kernel)
         for (int j = 0; j < J; ++j) {
             const int biA = bestK[j] & 8191;
-            double bT = biA == 8191 ? 0.0 : 2.0 * ((double)((bestK[j] >> 13) - 131072) * LN2 + log(bestM[j]));
+            int bE = bestK[j] >> 13;
+            double bM = bestM[j];
             int bL = biA == 8191 ? 0x7fffffff : biA * P.npairs + p;
             for (int off = 32; off > 0; off >>= 1) {
-                const double oT = __shfl_xor(bT, off);
+                const int oE = __shfl_xor(bE, off);
+                const double oM = __shfl_xor(bM, off);
                 const int oL = __shfl_xor(bL, off);
-                if (oT > bT || (oT == bT && oL < bL)) { bT = oT; bL = oL; }
+                if (oE > bE || (oE == bE && (oM > bM || (oM == bM && oL < bL)))) { bE = oE; bM = oM; bL = oL; }
             }
             if (lane == 0 && j < nvalid) {
                 const size_t o = (size_t)slice * P.M + (tb + j);   // [slice][M]
-                P.part_T[o] = bT;
+                P.part_T[o] = bM;
                 P.part_lin[o] = bL;
-                P.part_ns[o] = 0;
+                P.part_ns[o] = bE;
             }
         }
     }
 #ifdef BMX_PROFILE
     if (lane == 0 && P.prof)
-        for (int k = 0; k < 9; ++k) atomicAdd(P.prof + k, (unsigned long long)prof_[k]);
+        for (int k = 0; k < 12; ++k) atomicAdd(P.prof + k, (unsigned long long)prof_[k]);
+#endif
+#ifdef BMX_COUNT
+    if (lane == 0 && P.prof)
+        for (int k = 0; k < 16; ++k) atomicAdd(P.prof + 16 + k, cnt_[k]);
 #endif
 }
 
@@ -956,12 +1052,13 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 // i in [lo,hi], A*|g_i - t| <= zcut, g_i != t; it is monotone on either side of the test site.
 struct FinalParams {
     const double *part_T; const int32_t *part_lin; const int32_t *part_ns;
-    int nslices, npairs, recount;
+    int nslices, npairs, recount;   // recount != 0: grouped kernel -- parts hold (mantissa, index, clamped exponent + 2^17)
     int64_t M, N;
     const double *genpos, *A, *test_gen;
     const int64_t *win_lo, *win_hi, *center, *center_hi;
     double zcut;
     double *clr; int32_t *lin; int32_t *nsites;
+    bmx_record *rec;   // the same three values as one 16-byte record per test site (what the multi-GPU gather moves)
 };
 
 __global__ void finalize_kernel(FinalParams F) {
@@ -969,6 +1066,21 @@ __global__ void finalize_kernel(FinalParams F) {
     if (t >= F.M) return;
     double bT = 0.0;
     int bL = 0x7fffffff, bN = 0;
+    if (F.recount) {
+        double bM = 1.0;
+        int bE = 131072;
+        for (int s = 0; s < F.nslices; ++s) {
+            const double m = F.part_T[(size_t)s * F.M + t];
+            const int L = F.part_lin[(size_t)s * F.M + t];
+            const int e = F.part_ns[(size_t)s * F.M + t];
+            if (L != 0x7fffffff && (e > bE || (e == bE && (m > bM || (m == bM && L < bL))))) {
+                bM = m;
+                bE = e;
+                bL = L;
+            }
+        }
+        if (bL != 0x7fffffff) bT = 2.0 * ((double)(bE - 131072) * LN2 + log(bM));
+    } else
     for (int s = 0; s < F.nslices; ++s) {
         const double T = F.part_T[(size_t)s * F.M + t];
         const int L = F.part_lin[(size_t)s * F.M + t];
@@ -1002,6 +1114,7 @@ __global__ void finalize_kernel(FinalParams F) {
     F.clr[t] = none ? 0.0 : bT;
     F.lin[t] = none ? -1 : bL;
     F.nsites[t] = none ? 0 : bN;
+    F.rec[t] = bmx_record{none ? 0.0 : bT, none ? -1 : bL, none ? 0 : bN};
 }
 
 // ----------------------------------------------------------------------------- surface
@@ -1066,12 +1179,60 @@ void dfree(T *&p) {
 
 }  // namespace
 
+
+// bmx_io.cpp: rows [0, n) formatted into `out` (<= 512 bytes per row); grid indices either as (ix, ia, iA) or as the
+// linear index lin = (iA*nx + ix)*nab + ia (< 0: the reference's all-zero row).  Returns the bytes written, 0 on a bad index.
+struct bmx_row_tables_;
+extern "C" bmx_row_tables_ *bmx_row_tables_new_(const char *xs, int nx, const char *abs_, int nab, const char *As, int nA);
+extern "C" void bmx_row_tables_free_(bmx_row_tables_ *t);
+extern "C" int bmx_write_chunk_(FILE *f, const bmx_row_tables_ *t, int64_t n, const int64_t *phys, const double *gen, const double *clr,
+                                const int32_t *ix, const int32_t *ia, const int32_t *iA, const int32_t *lin, const int32_t *nsites);
+
 // =================================================================================== ctx
+namespace {
+
+// Device buffer that only grows: set_sites / set_tests / surface of a long run (22 chromosomes, thousands of surfaces)
+// reuse their allocations instead of paying hipMalloc/hipFree per call.
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(n, 1);
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// fn(t, begin, end) on T host threads over [0, n)
+template <class F>
+void parallel_ranges(int64_t n, int64_t grain, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, 32), n / std::max<int64_t>(grain, 1) + 1);
+    if (T <= 1) { fn(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(fn, t, n * t / T, n * (t + 1) / T);
+    for (auto &x : th) x.join();
+}
+
+}  // namespace
+
 struct bmx_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    bool timed = false;         // a scan has been launched since the test sites were set: results / events are valid
     int variant = 0;
     // model
     bool has_model = false;
@@ -1080,59 +1241,72 @@ struct bmx_ctx {
     double rmax = 0.0;
     int32_t *d_sizes = nullptr, *d_row_off = nullptr;
     double *d_g = nullptr, *d_prop = nullptr, *d_x = nullptr, *d_abeta = nullptr, *d_A = nullptr;
-    double *d_psel = nullptr, *d_R = nullptr, *d_Rt = nullptr, *d_rowmax = nullptr;
+    double *d_psel = nullptr, *d_R = nullptr, *d_Rt = nullptr;
     std::vector<double> h_A, h_rowmax;   // h_rowmax: [nslices][rows] max |R| (+inf: absent row)
-    // far-field moment slots: the data's most frequent rows (set_sites)
-    uint8_t *d_kmom = nullptr;
-    unsigned long long *d_prof = nullptr;   // -DBMX_PROFILE builds
-    int row_of_slot[MOM_SLOTS] = {0};
     uint64_t *d_patch_x = nullptr;
     double *d_patch_y = nullptr;
     int n_patch = 0;
     std::vector<double> h_g;
-    // sites
+    // sites (grow-only buffers)
     bool has_sites = false;
     int64_t N = 0;
-    double *d_genpos = nullptr;
-    uint16_t *d_row = nullptr;      // one of the two is used
-    uint32_t *d_row32 = nullptr;
+    DevBuf<double> genpos, rowmax;
+    DevBuf<uint16_t> row16;      // one of the two is used
+    DevBuf<uint32_t> row32;
+    bool wide_rows = false;
+    DevBuf<uint8_t> kmom;        // far-field moment slots that pay at each A (set_sites)
+    int row_of_slot[MOM_SLOTS] = {0};
+    unsigned long long *d_prof = nullptr;   // -DBMX_PROFILE / -DBMX_COUNT builds
     // tests
     bool has_tests = false;
     int64_t M = 0;
-    double *d_test_gen = nullptr;
-    int64_t *d_win_lo = nullptr, *d_win_hi = nullptr, *d_center = nullptr, *d_center_hi = nullptr;
+    DevBuf<double> test_gen;
+    DevBuf<int64_t> win_lo, win_hi, center, center_hi;
     bool tests_sorted = false;
     int64_t test_gap = 1 << 30;  // median index gap between neighbouring test sites (sampled)
-    double *d_part_T = nullptr;
-    int32_t *d_part_lin = nullptr, *d_part_ns = nullptr;
-    double *d_clr = nullptr;
-    int32_t *d_lin = nullptr, *d_nsites = nullptr;
+    // per-slice winners of one launch range, results of all test sites
+    DevBuf<double> part_T;
+    DevBuf<int32_t> part_lin, part_ns;
+    DevBuf<double> clr;
+    DevBuf<int32_t> lin, nsites;
+    DevBuf<bmx_record> rec;
+    DevBuf<double> surf_T;
+    DevBuf<int32_t> surf_ns;
+    // pinned host staging of the streaming writer: two slots of (clr, lin, nsites)
+    void *h_stage[2] = {nullptr, nullptr};
+    size_t h_stage_cap = 0;
     double zcut = 0;
+    double last_ms = 0.0;
 };
 
 namespace {
 
 void free_model(bmx_ctx *c) {
     dfree(c->d_sizes); dfree(c->d_row_off); dfree(c->d_g); dfree(c->d_prop); dfree(c->d_x);
-    dfree(c->d_abeta); dfree(c->d_A); dfree(c->d_psel); dfree(c->d_R); dfree(c->d_Rt); dfree(c->d_rowmax);
+    dfree(c->d_abeta); dfree(c->d_A); dfree(c->d_psel); dfree(c->d_R); dfree(c->d_Rt);
     dfree(c->d_patch_x); dfree(c->d_patch_y);
     c->has_model = false;
 }
-void free_sites(bmx_ctx *c) {
-    dfree(c->d_genpos); dfree(c->d_row); dfree(c->d_row32); dfree(c->d_kmom);
-    c->has_sites = false;
-}
-void free_tests(bmx_ctx *c) {
-    dfree(c->d_test_gen); dfree(c->d_win_lo); dfree(c->d_win_hi); dfree(c->d_center); dfree(c->d_center_hi);
-    dfree(c->d_part_T); dfree(c->d_part_lin); dfree(c->d_part_ns);
-    dfree(c->d_clr); dfree(c->d_lin); dfree(c->d_nsites);
+// sites / tests: the buffers stay allocated for the next chromosome; only the state is dropped
+void drop_tests(bmx_ctx *c) {
     c->has_tests = false;
+    c->timed = false;       // results belong to the test sites they were computed for
+}
+void drop_sites(bmx_ctx *c) {
+    c->has_sites = false;
+    drop_tests(c);          // test sites were located in the old site array
 }
 
 template <class T>
 int upload(T *&dst, const T *src, size_t n, hipStream_t s) {
     HIP_TRY(hipMalloc((void **)&dst, std::max<size_t>(n, 1) * sizeof(T)));
     if (n) HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+    return BMX_OK;
+}
+template <class T>
+int upload(DevBuf<T> &dst, const T *src, size_t n, hipStream_t s) {
+    HIP_TRY(dst.ensure(n));
+    if (n) HIP_TRY(hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
     return BMX_OK;
 }
 
@@ -1166,6 +1340,13 @@ void bmx_version(int *major, int *minor) {
     if (minor) *minor = BMX_ABI_VERSION_MINOR;
 }
 
+/* A short hash of the kernel source this binary was built from (Makefile: -DBMX_SRC_HASH): the Python shim and the
+ * tests compare it with the source in the tree, so that a stale libbmxscan.so cannot be tested or benchmarked. */
+#ifndef BMX_SRC_HASH
+#define BMX_SRC_HASH "unknown"
+#endif
+const char *bmx_build_id(void) { return BMX_SRC_HASH; }
+
 const char *bmx_last_error(void) { return g_err.c_str(); }
 void bmx_set_error_(const char *msg) { g_err = msg ? msg : ""; }   // for the library's other translation units
 
@@ -1188,9 +1369,13 @@ int bmx_ctx_create(bmx_ctx **out, int device) {
     bmx_ctx *c = new bmx_ctx();
     c->device = device;
     c->zcut = compute_zcut();
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-        hipEventCreate(&c->ev1) != hipSuccess) {
-        delete c;
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipStreamCreate(&c->copy_stream) == hipSuccess &&
+              hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    for (int k = 0; ok && k < 2; k++)
+        ok = hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_copied[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        bmx_ctx_destroy(c);
         return fail(BMX_E_HIP, "stream/event creation failed");
     }
     TRACE("ctx_create: done");
@@ -1201,13 +1386,24 @@ int bmx_ctx_create(bmx_ctx **out, int device) {
 void bmx_ctx_destroy(bmx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     free_model(c);
-    free_sites(c);
-    free_tests(c);
+    c->genpos.release(); c->rowmax.release(); c->row16.release(); c->row32.release(); c->kmom.release();
+    c->test_gen.release(); c->win_lo.release(); c->win_hi.release(); c->center.release(); c->center_hi.release();
+    c->part_T.release(); c->part_lin.release(); c->part_ns.release();
+    c->clr.release(); c->lin.release(); c->nsites.release(); c->rec.release();
+    c->surf_T.release(); c->surf_ns.release();
+    dfree(c->d_prof);
+    for (int k = 0; k < 2; k++) {
+        if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
+        if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
+        if (c->ev_copied[k]) (void)hipEventDestroy(c->ev_copied[k]);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
 }
 
@@ -1228,8 +1424,7 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_model(c);
-    free_sites(c);      // row indices and the moment slots belong to the model they were set under
-    free_tests(c);
+    drop_sites(c);      // row indices and the moment slots belong to the model they were set under
     c->stat = m->stat; c->min_count = m->min_count; c->n_sizes = m->n_sizes;
     c->rows = m->row_off[m->n_sizes]; c->nx = m->nx; c->nab = m->nab; c->nA = nA;
     c->npairs = m->nx * m->nab;
@@ -1342,35 +1537,55 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
     if (!c->has_model) return fail(BMX_E_STATE, "set_model must precede set_sites");
     if (N < 1 || !genpos || !row) return fail(BMX_E_INVALID, "empty site arrays");
+    if (N >= 0x7fffffffLL) return fail(BMX_E_LIMIT, "more than 2^31 sites in one array (scan chromosomes one at a time)");
+    // One pass on the host's cores: every row index inside the table and on a (k, n) with a positive neutral probability
+    // (the kernels index the LDS/L2 table with it unchecked), positions sorted and not NaN; 16-bit row indices and the
+    // per-row site counts (moment slots) come out of the same pass.
     const bool wide = c->rows > 65535;
     std::vector<uint16_t> r16(wide ? 0 : (size_t)N);
     std::vector<uint32_t> r32(wide ? (size_t)N : 0);
-    for (int64_t i = 0; i < N; i++) {
-        if (row[i] < 0 || row[i] >= c->rows) return fail(BMX_E_INVALID, "site row index outside the LUT");
-        if (!(c->h_g[(size_t)row[i]] > 0.0))
-            return fail(BMX_E_INVALID, "a site has a (count, sample size) whose neutral probability is missing or not positive");
-        if (i && genpos[i] < genpos[i - 1]) return fail(BMX_E_INVALID, "genetic positions must be non-decreasing");
-        if (!(genpos[i] == genpos[i])) return fail(BMX_E_INVALID, "NaN genetic position");
-        if (wide) r32[(size_t)i] = (uint32_t)row[i]; else r16[(size_t)i] = (uint16_t)row[i];
+    constexpr int MAXT = 32;
+    int bad[MAXT];
+    std::vector<int64_t> cnt_t[MAXT];
+    for (int t = 0; t < MAXT; t++) bad[t] = 0;
+    parallel_ranges(N, 1 << 18, [&](int t, int64_t b, int64_t e) {
+        std::vector<int64_t> &cnt = cnt_t[t];
+        cnt.assign((size_t)c->rows, 0);
+        for (int64_t i = b; i < e; i++) {
+            const int32_t r = row[i];
+            if (r < 0 || r >= c->rows) { bad[t] = 1; return; }
+            if (!(c->h_g[(size_t)r] > 0.0)) { bad[t] = 2; return; }
+            if (i && genpos[i] < genpos[i - 1]) { bad[t] = 3; return; }
+            if (!(genpos[i] == genpos[i])) { bad[t] = 4; return; }
+            if (wide) r32[(size_t)i] = (uint32_t)r; else r16[(size_t)i] = (uint16_t)r;
+            cnt[(size_t)r]++;
+        }
+    });
+    for (int t = 0; t < MAXT; t++) {
+        if (bad[t] == 1) return fail(BMX_E_INVALID, "site row index outside the LUT");
+        if (bad[t] == 2) return fail(BMX_E_INVALID, "a site has a (count, sample size) whose neutral probability is missing or not positive");
+        if (bad[t] == 3) return fail(BMX_E_INVALID, "genetic positions must be non-decreasing");
+        if (bad[t] == 4) return fail(BMX_E_INVALID, "NaN genetic position");
     }
+    std::vector<int64_t> cnt((size_t)c->rows, 0);
+    for (int t = 0; t < MAXT; t++)
+        for (size_t r = 0; r < cnt_t[t].size(); r++) cnt[r] += cnt_t[t][r];
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    free_sites(c);
-    free_tests(c);      // test sites were located in the old site array
+    drop_sites(c);
     int rc;
-    if ((rc = upload(c->d_genpos, genpos, (size_t)N, c->stream))) return rc;
+    if ((rc = upload(c->genpos, genpos, (size_t)N, c->stream))) return rc;
     if (wide) {
-        if ((rc = upload(c->d_row32, (const uint32_t *)r32.data(), (size_t)N, c->stream))) return rc;
+        if ((rc = upload(c->row32, (const uint32_t *)r32.data(), (size_t)N, c->stream))) return rc;
     } else {
-        if ((rc = upload(c->d_row, (const uint16_t *)r16.data(), (size_t)N, c->stream))) return rc;
+        if ((rc = upload(c->row16, (const uint16_t *)r16.data(), (size_t)N, c->stream))) return rc;
     }
+    c->wide_rows = wide;
     {
         // Moment slots for the grouped kernel's far field: rank the rows by how many sites carry them.
         // Slot s pays at a given A when the ~23 instructions saved per far site of that row outweigh
         // the ~30 instructions its term costs at the end of each zone; the expected number of far sites
         // per zone follows from the mean site density (a performance heuristic only: any choice is exact).
-        std::vector<int64_t> cnt((size_t)c->rows, 0);
-        for (int64_t i = 0; i < N; i++) cnt[(size_t)row[i]]++;
         std::vector<int> order((size_t)c->rows);
         for (int r = 0; r < c->rows; r++) order[(size_t)r] = r;
         const size_t ns = std::min((size_t)MOM_SLOTS, order.size());
@@ -1385,7 +1600,7 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
             nslots = (int)k + 1;
         }
         for (int k = nslots; k < MOM_SLOTS; k++) c->row_of_slot[k] = nslots ? c->row_of_slot[0] : 0;
-        const int kcap = getenv("BMX_MOM_SLOTS") ? std::min(atoi(getenv("BMX_MOM_SLOTS")), MOM_SLOTS) : MOM_SLOTS;   // experiments
+        const int kcap = diag_env("BMX_MOM_SLOTS") ? std::min(std::max(atoi(diag_env("BMX_MOM_SLOTS")), 0), MOM_SLOTS) : MOM_SLOTS;
         const double range = genpos[N - 1] - genpos[0];
         std::vector<uint8_t> km((size_t)c->nA, 0);
         for (int a = 0; a < c->nA; a++) {
@@ -1403,11 +1618,10 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
             bits = ((bits & ~0xffull) + 0x100ull) | slot[k % (size_t)c->rows];
             memcpy(&packed[k], &bits, sizeof bits);
         }
-        dfree(c->d_rowmax);
-        if ((rc = upload(c->d_rowmax, (const double *)packed.data(), packed.size(), c->stream))) return rc;
-        if ((rc = upload(c->d_kmom, (const uint8_t *)km.data(), km.size(), c->stream))) return rc;
+        if ((rc = upload(c->rowmax, (const double *)packed.data(), packed.size(), c->stream))) return rc;
+        if ((rc = upload(c->kmom, (const uint8_t *)km.data(), km.size(), c->stream))) return rc;
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));     // the staging vectors go out of scope here
     c->N = N;
     c->has_sites = true;
     return BMX_OK;
@@ -1420,32 +1634,33 @@ int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64
     if (M < 1 || !test_gen || !win_lo || !win_hi) return fail(BMX_E_INVALID, "empty test-site arrays");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    free_tests(c);
+    drop_tests(c);
     int rc;
-    if ((rc = upload(c->d_test_gen, test_gen, (size_t)M, c->stream))) return rc;
-    if ((rc = upload(c->d_win_lo, win_lo, (size_t)M, c->stream))) return rc;
-    if ((rc = upload(c->d_win_hi, win_hi, (size_t)M, c->stream))) return rc;
-    HIP_TRY(hipMalloc((void **)&c->d_center, (size_t)M * sizeof(int64_t)));
-    HIP_TRY(hipMalloc((void **)&c->d_center_hi, (size_t)M * sizeof(int64_t)));
-    c->tests_sorted = true;   // the grouped kernel needs ascending test positions
-    for (int64_t t = 1; t < M; t++)
-        if (!(test_gen[t] >= test_gen[t - 1])) { c->tests_sorted = false; break; }
-    size_t np = (size_t)M * c->nslices;
-    HIP_TRY(hipMalloc((void **)&c->d_part_T, np * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&c->d_part_lin, np * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void **)&c->d_part_ns, np * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void **)&c->d_clr, (size_t)M * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&c->d_lin, (size_t)M * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void **)&c->d_nsites, (size_t)M * sizeof(int32_t)));
+    if ((rc = upload(c->test_gen, test_gen, (size_t)M, c->stream))) return rc;
+    if ((rc = upload(c->win_lo, win_lo, (size_t)M, c->stream))) return rc;
+    if ((rc = upload(c->win_hi, win_hi, (size_t)M, c->stream))) return rc;
+    HIP_TRY(c->center.ensure((size_t)M));
+    HIP_TRY(c->center_hi.ensure((size_t)M));
+    HIP_TRY(c->clr.ensure((size_t)M));
+    HIP_TRY(c->lin.ensure((size_t)M));
+    HIP_TRY(c->nsites.ensure((size_t)M));
+    HIP_TRY(c->rec.ensure((size_t)M));
     int threads = 256;
     hipLaunchKernelGGL(locate_kernel, dim3((unsigned)((M + threads - 1) / threads)), dim3(threads), 0, c->stream,
-                       c->d_genpos, c->N, c->d_test_gen, M, c->d_center, c->d_center_hi);
+                       c->genpos.p, c->N, c->test_gen.p, M, c->center.p, c->center_hi.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // while the device locates the test sites: the grouped kernel needs ascending test positions
+    int unsorted = 0;
+    parallel_ranges(M, 1 << 18, [&](int, int64_t b, int64_t e) {
+        for (int64_t t = std::max<int64_t>(b, 1); t < e; t++)
+            if (!(test_gen[t] >= test_gen[t - 1])) { unsorted = 1; return; }
+    });
+    c->tests_sorted = !unsorted;
     {   // test-site density from a sample of the located positions (decides grouped vs per-site kernel)
         const int64_t ns = std::min<int64_t>(M, 65536);
         std::vector<int64_t> hc((size_t)ns);
-        HIP_TRY(hipMemcpy(hc.data(), c->d_center, (size_t)ns * sizeof(int64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(hc.data(), c->center.p, (size_t)ns * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
         std::vector<int64_t> gaps;
         for (int64_t t = 1; t < ns; t++) gaps.push_back(hc[(size_t)t] - hc[(size_t)t - 1]);
         c->test_gap = 1 << 30;
@@ -1459,54 +1674,63 @@ int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64
     return BMX_OK;
 }
 
-int bmx_ctx_scan(bmx_ctx *c) {
-    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
-    if (!c->has_model || !c->has_sites || !c->has_tests) return fail(BMX_E_STATE, "model, sites and tests must be set before scan");
-    HIP_TRY(hipSetDevice(c->device));
+}  // extern "C"
+
+namespace {
+
+// Everything a launch of the scan needs that does not depend on which test sites it covers.
+struct ScanPlan {
     ScanParams P;
-    P.genpos = c->d_genpos; P.row = RowArray{c->d_row, c->d_row32}; P.N = c->N; P.Rt = c->d_Rt;
+    const void *fn = nullptr;
+    int J = 0, threads = SCAN_THREADS;
+    size_t lds_bytes = 0;
+    int spb = 0;            // test sites per workgroup
+    int64_t range = 0;      // test sites per launch (multiple of spb): bounds the per-slice winner arrays
+};
+
+int plan_scan(bmx_ctx *c, ScanPlan &pl) {
+    ScanParams &P = pl.P;
+    P.genpos = c->genpos.p; P.row = RowArray{c->wide_rows ? nullptr : c->row16.p, c->wide_rows ? c->row32.p : nullptr}; P.N = c->N; P.Rt = c->d_Rt;
     P.rows = c->rows; P.NP = c->NP; P.npairs = c->npairs; P.nslices = c->nslices;
-    P.A = c->d_A; P.nA = c->nA; P.test_gen = c->d_test_gen; P.win_lo = c->d_win_lo; P.win_hi = c->d_win_hi;
-    P.center = c->d_center; P.center_hi = c->d_center_hi; P.M = c->M; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi; P.rmax = c->rmax;
+    P.A = c->d_A; P.nA = c->nA; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi; P.rmax = c->rmax;
     {
-        // series cut at |x|^(order+1)/(order+1) <= ~6e-15 for the nearest far site
-        const double eps_default = FAR_ORDER >= 8 ? 0.0296 : FAR_ORDER >= 6 ? 0.0105 : 0.0016;
-        double eps = getenv("BMX_FAR_EPS") ? atof(getenv("BMX_FAR_EPS")) : eps_default;   // accuracy experiments
-        eps = std::min(std::max(eps, 0.0), 0.035);
+        // 8th order: economised coefficients, valid on [-0.05, 0.05] (FAR_W); lower orders: Taylor, cut at ~6e-15
+        const double eps_default = FAR_ORDER >= 8 ? 0.05 : FAR_ORDER >= 6 ? 0.0105 : 0.0016;
+        double eps = diag_env("BMX_FAR_EPS") ? atof(diag_env("BMX_FAR_EPS")) : eps_default;   // accuracy experiments
+        eps = std::min(std::max(eps, 0.0), FAR_ORDER >= 8 ? 0.05 : 0.035);
         P.far_eps = eps;
-        P.rowmax = c->d_rowmax;
-        P.kmom = c->d_kmom;
+        P.rowmax = c->rowmax.p;
+        P.kmom = c->kmom.p;
         P.prof = nullptr;
-#ifdef BMX_PROFILE
-        if (!c->d_prof) { HIP_TRY(hipMalloc((void **)&c->d_prof, 9 * sizeof(unsigned long long))); HIP_TRY(hipMemset(c->d_prof, 0, 9 * sizeof(unsigned long long))); }
+#if defined(BMX_PROFILE) || defined(BMX_COUNT)
+        if (!c->d_prof) { HIP_TRY(hipMalloc((void **)&c->d_prof, 32 * sizeof(unsigned long long))); HIP_TRY(hipMemset(c->d_prof, 0, 32 * sizeof(unsigned long long))); }
         P.prof = c->d_prof;
 #endif
         for (int k = 0; k < MOM_SLOTS; k++) P.row_of_slot[k] = c->row_of_slot[k];
-        P.far_bits = (float)(eps * 1.4427 * 1.02);      // |log1p(x)| <= 1.02 |x| for |x| <= 0.035
+        P.far_bits = (float)(eps * 1.4427 * 1.03);      // |log1p(x)| <= 1.027 |x| for |x| <= 0.05
     }
-    P.part_T = c->d_part_T; P.part_lin = c->d_part_lin; P.part_ns = c->d_part_ns;
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
-    if (const char *pad = getenv("BMX_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments
+    if (const char *pad = diag_env("BMX_LDS_PAD")) lds += (size_t)std::max(atoi(pad), 0);   // occupancy experiments
     // moment slots per wave: as many (64, 32, 16, 8, 0) as leave the R slice in LDS; when the table is
     // too large for LDS anyway (many sample sizes: the sites spread over many rows), all MOM_SLOTS
     int mom_slots = MOM_SLOTS_LDS;
+    auto wave_bytes = [&](int slots) {
+        return WAVE * sizeof(ScratchEnt) + (size_t)(slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double) + (size_t)MID_CAP * 12;
+    };
     auto lds_need = [&](int slots) {
-        return lds + (size_t)(c->rows + 2) * sizeof(double) +
-               (size_t)(SCAN_THREADS_MAX / WAVE) * (WAVE * sizeof(ScratchEnt) + (size_t)(slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double));
+        return lds + (size_t)(c->rows + 2) * sizeof(double) + (size_t)(SCAN_THREADS_MAX / WAVE) * wave_bytes(slots);
     };
     while (mom_slots >= 8 && lds_need(mom_slots) > (size_t)LDS_LIMIT_BYTES) mom_slots /= 2;
     if (mom_slots < 8) mom_slots = 0;
     const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES;
     if (!fits || c->variant == 1) mom_slots = MOM_SLOTS;
     P.mom_slots = mom_slots;
-    // grouping pays when neighbouring test sites share most of their windows; a strided scan
-    // (-s far larger than 1) is better served one test site per wave
     // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3
     // (windows/s x1000 for J = 16 / 8 / 4 / per-site): stride 1: 2537/-/-/-, 2: 2221/1800, 3: 1899/1706,
     // 4: 1540/1630/1124, 8: 1073/1299/1031, 16: 733/960/883, 32: 470/693/703, 64: 298/460/540,
     // 128: 180/307/384/340, 160: -/-/335/338, 200: -/-/316/335 -> J by the median gap between test sites;
     // beyond ~150 sites the per-site kernel takes over.
-    const int64_t gap_max = getenv("BMX_DENSE_GAP") ? atoll(getenv("BMX_DENSE_GAP")) : 150;
+    const int64_t gap_max = diag_env("BMX_DENSE_GAP") ? atoll(diag_env("BMX_DENSE_GAP")) : 150;
     const bool can_group = c->tests_sorted && c->test_gap <= gap_max && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
     int J = 0;
     // variants (A/B runs): 0 -> J by test-site gap, pairs near / quads mid / power sums far (default);
@@ -1516,20 +1740,20 @@ int bmx_ctx_scan(bmx_ctx *c) {
         const int v = c->variant;
         J = (v == 0 || v == 5 || v == 8 || v == 10) ? 16 : (v == 3 || v == 6 || v == 9 || v == 11) ? 8 : (v == 4 || v == 7) ? 4 : 0;
         if (v == 0) J = c->test_gap <= 3 ? 16 : c->test_gap <= 28 ? 8 : 4;
-        if (v == 0 && getenv("BMX_FORCE_J")) J = atoi(getenv("BMX_FORCE_J"));   // threshold experiments: 16, 8 or 4
+        if (v == 0 && diag_env("BMX_FORCE_J")) {                                  // threshold experiments: 16, 8 or 4
+            const int fj = atoi(diag_env("BMX_FORCE_J"));
+            if (fj != 16 && fj != 8 && fj != 4) return fail(BMX_E_INVALID, "BMX_FORCE_J must be 16, 8 or 4");
+            J = fj;
+        }
     }
-    P.sites_per_block = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : 4);
-    if (J == 16 && P.sites_per_block < 64) P.sites_per_block = 64;
-    int64_t chunks = (c->M + P.sites_per_block - 1) / P.sites_per_block;
-    int64_t blocks = chunks * c->nslices;
-    if (blocks > 0x7fffffffLL) return fail(BMX_E_LIMIT, "too many workgroups; split the test sites");
-    bool use_lds = fits && c->variant != 1;
-    TRACE("scan: %lld blocks, lds=%zu use_lds=%d span_hi=%d spb=%d J=%d", (long long)blocks, lds, (int)use_lds, c->span_hi, P.sites_per_block, J);
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    int spb = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : 4);
+    if (J == 16 && spb < 64) spb = 64;
+    if (J && diag_env("BMX_SPB")) spb = std::max(4 * J, atoi(diag_env("BMX_SPB")) / (4 * J) * (4 * J));   // experiments
+    const bool use_lds = fits && c->variant != 1;
     const void *fn = nullptr;
 #define PICK(K) (use_lds ? (const void *)K<true> : (const void *)K<false>)
     // inner-loop form: 0 readlane / one site per step; 1 LDS broadcast + pairs; 2 = 1 + four sites per
-    // step where every alpha <= 1/2; 3 (default) = 2 + power sums where alpha*max|R| <= far_eps
+    // step where alpha <= 1/2; 3 (default) = 2 + power sums where alpha*max|R| <= far_eps
     const int mode = (c->variant >= 5 && c->variant <= 7) ? 0 : (c->variant >= 8 && c->variant <= 9) ? 1 : (c->variant >= 10 && c->variant <= 11) ? 2 : 3;
 #define GP2(JJ, MM) (use_lds ? (const void *)clr_scan_grouped_kernel<JJ, true, MM> : (const void *)clr_scan_grouped_kernel<JJ, false, MM>)
 #define GPICK(JJ) (mode == 3 ? GP2(JJ, 3) : mode == 2 ? GP2(JJ, 2) : mode == 1 ? GP2(JJ, 1) : GP2(JJ, 0))
@@ -1543,32 +1767,69 @@ int bmx_ctx_scan(bmx_ctx *c) {
     // One wave per SIMD issues FP64 at half rate (measured), so a workgroup whose LDS footprint
     // allows only one resident workgroup per CU gets 8 waves instead of 4.
     int threads = SCAN_THREADS;
-    // grouped kernels: per-row max |R| (+ moment slot) behind the slice, moments behind the scratch
+    // grouped kernels: per-row max |R| (+ moment slot) behind the slice, then per wave the scratch list, the moments
+    // and the staged sites between the test sites
     const size_t lds_rm = (size_t)((c->rows + 1) & ~1) * sizeof(double);
-    const size_t lds_wave = WAVE * sizeof(ScratchEnt) + (size_t)(mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double);
-    size_t lds_bytes = (use_lds ? lds + (J ? lds_rm : 0) : 0) + (J ? (size_t)(threads / WAVE) * lds_wave : 0);
+    size_t lds_bytes = (use_lds ? lds + (J ? lds_rm : 0) : 0) + (J ? (size_t)(threads / WAVE) * wave_bytes(mom_slots) : 0);
     if (J && 2 * lds_bytes > (size_t)LDS_LIMIT_BYTES) {
         threads = SCAN_THREADS_MAX;
-        lds_bytes = (use_lds ? lds + lds_rm : 0) + (size_t)(threads / WAVE) * lds_wave;
-        P.sites_per_block *= 2;
-        chunks = (c->M + P.sites_per_block - 1) / P.sites_per_block;
-        blocks = chunks * c->nslices;
+        lds_bytes = (use_lds ? lds + lds_rm : 0) + (size_t)(threads / WAVE) * wave_bytes(mom_slots);
+        spb *= 2;
     }
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return fail(BMX_E_LIMIT, "LDS budget exceeded");
     if (lds_bytes) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    P.sites_per_block = spb;
+    pl.fn = fn; pl.J = J; pl.threads = threads; pl.lds_bytes = lds_bytes; pl.spb = spb;
+    // test sites per launch: keeps the per-slice winners (16 B x slices per test site) within ~256 MB and the grid
+    // within 2^31 workgroups; a multiple of the workgroup's share, so ranges cut the test sites where workgroups do
+    int64_t range = std::max<int64_t>((int64_t)(256u << 20) / (16 * (int64_t)c->nslices), spb);
+    range = std::min<int64_t>(range, (int64_t)0x7fffff00LL / c->nslices * spb);
+    range = std::max<int64_t>(range / spb, 1) * spb;
+    pl.range = range;
+    TRACE("scan plan: lds=%zu use_lds=%d span_hi=%d spb=%d J=%d threads=%d range=%lld", lds_bytes, (int)use_lds, c->span_hi, spb, J, threads, (long long)range);
+    return BMX_OK;
+}
+
+// scan + finalize of test sites [off, off + cnt) on the context's stream (asynchronous)
+int launch_range(bmx_ctx *c, ScanPlan &pl, int64_t off, int64_t cnt) {
+    ScanParams &P = pl.P;
+    const size_t np = (size_t)cnt * c->nslices;
+    HIP_TRY(c->part_T.ensure(np));
+    HIP_TRY(c->part_lin.ensure(np));
+    HIP_TRY(c->part_ns.ensure(np));
+    P.test_gen = c->test_gen.p + off; P.win_lo = c->win_lo.p + off; P.win_hi = c->win_hi.p + off;
+    P.center = c->center.p + off; P.center_hi = c->center_hi.p + off; P.M = cnt;
+    P.part_T = c->part_T.p; P.part_lin = c->part_lin.p; P.part_ns = c->part_ns.p;
+    const int64_t blocks = (cnt + pl.spb - 1) / pl.spb * c->nslices;
     void *kargs[] = {&P};
-    TRACE("scan: launch %lld blocks x %d threads, %zu B LDS", (long long)blocks, threads, lds_bytes);
-    HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(threads), kargs, lds_bytes, c->stream));
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipLaunchKernel(pl.fn, dim3((unsigned)blocks), dim3(pl.threads), kargs, pl.lds_bytes, c->stream));
     FinalParams F;
-    F.part_T = c->d_part_T; F.part_lin = c->d_part_lin; F.part_ns = c->d_part_ns;
-    F.nslices = c->nslices; F.npairs = c->npairs; F.recount = J ? 1 : 0; F.M = c->M; F.N = c->N;
-    F.genpos = c->d_genpos; F.A = c->d_A; F.test_gen = c->d_test_gen; F.win_lo = c->d_win_lo; F.win_hi = c->d_win_hi;
-    F.center = c->d_center; F.center_hi = c->d_center_hi; F.zcut = c->zcut;
-    F.clr = c->d_clr; F.lin = c->d_lin; F.nsites = c->d_nsites;
+    F.part_T = c->part_T.p; F.part_lin = c->part_lin.p; F.part_ns = c->part_ns.p;
+    F.nslices = c->nslices; F.npairs = c->npairs; F.recount = pl.J ? 1 : 0; F.M = cnt; F.N = c->N;
+    F.genpos = c->genpos.p; F.A = c->d_A; F.test_gen = P.test_gen; F.win_lo = P.win_lo; F.win_hi = P.win_hi;
+    F.center = P.center; F.center_hi = P.center_hi; F.zcut = c->zcut;
+    F.clr = c->clr.p + off; F.lin = c->lin.p + off; F.nsites = c->nsites.p + off; F.rec = c->rec.p + off;
     const int fthreads = 256;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((c->M + fthreads - 1) / fthreads)), dim3(fthreads), 0, c->stream, F);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((cnt + fthreads - 1) / fthreads)), dim3(fthreads), 0, c->stream, F);
     HIP_TRY(hipGetLastError());
+    return BMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bmx_ctx_scan(bmx_ctx *c) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    if (!c->has_model || !c->has_sites || !c->has_tests) return fail(BMX_E_STATE, "model, sites and tests must be set before scan");
+    HIP_TRY(hipSetDevice(c->device));
+    ScanPlan pl;
+    int rc = plan_scan(c, pl);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int64_t off = 0; off < c->M; off += pl.range)
+        if ((rc = launch_range(c, pl, off, std::min(pl.range, c->M - off)))) return rc;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     return BMX_OK;
 }
@@ -1577,16 +1838,24 @@ int bmx_ctx_sync(bmx_ctx *c) {
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-#ifdef BMX_PROFILE
+#if defined(BMX_PROFILE) || defined(BMX_COUNT)
     if (c->d_prof) {
-        unsigned long long h[9];
+        unsigned long long h[32];
         HIP_TRY(hipMemcpy(h, c->d_prof, sizeof h, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(c->d_prof, 0, sizeof h));
+#ifdef BMX_COUNT
+        static const char *cn[16] = {"bulk passes with sites", "passes with a near list", "quad blocks", "pair blocks", "near-list sites",
+                                     "far (moment) sites", "generic passes with sites", "generic passes", "zones folded/flushed",
+                                     "fold slots non-empty", "fold slots scanned (kmom)", "ragged zones", "generic walk passes",
+                                     "bulk pass iterations", "bulk sites", "zones"};
+        for (int k = 0; k < 16; k++) fprintf(stderr, "[bmx count] %-28s %llu\n", cn[k], h[16 + k]);
+#endif
         double tot = 0;
-        for (int k = 0; k < 9; k++) tot += (double)h[k];
-        static const char *nm[9] = {"between test sites", "zone set-up", "per-pass work", "near-list products", "ragged-end masks",
-                                    "fold of moments", "flush", "generic walks past zones", "best-tracking"};
-        if (tot > 0) for (int k = 0; k < 9; k++) fprintf(stderr, "[bmx prof] %-26s %5.1f %%\n", nm[k], 100.0 * (double)h[k] / tot);
+        for (int k = 0; k < 12; k++) tot += (double)h[k];
+        static const char *nm[12] = {"between test sites", "zone set-up", "per-pass: rank, list position, tail", "near-list block loops", "ragged-end masks",
+                                    "fold of moments", "flush", "generic walks past zones", "best-tracking", "near-list set-up",
+                                    "per-pass: loads, exp, classify", "per-pass: moment adds"};
+        if (tot > 0) for (int k = 0; k < 12; k++) fprintf(stderr, "[bmx prof] %-36s %5.1f %%\n", nm[k], 100.0 * (double)h[k] / tot);
     }
 #endif
     return BMX_OK;
@@ -1604,10 +1873,26 @@ int bmx_ctx_last_scan_ms(bmx_ctx *c, double *ms) {
 
 int bmx_ctx_result_ptrs(bmx_ctx *c, void **d_clr, void **d_lin, void **d_nsites) {
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
-    if (!c->has_tests) return fail(BMX_E_STATE, "no test sites set");
-    if (d_clr) *d_clr = c->d_clr;
-    if (d_lin) *d_lin = c->d_lin;
-    if (d_nsites) *d_nsites = c->d_nsites;
+    if (!c->has_tests || !c->timed) return fail(BMX_E_STATE, "no scan results: call bmx_ctx_scan after bmx_ctx_set_tests");
+    if (d_clr) *d_clr = c->clr.p;
+    if (d_lin) *d_lin = c->lin.p;
+    if (d_nsites) *d_nsites = c->nsites.p;
+    return BMX_OK;
+}
+
+int bmx_ctx_records(bmx_ctx *c, void **d_rec) {
+    if (!c || !d_rec) return fail(BMX_E_INVALID, "NULL argument");
+    if (!c->has_tests || !c->timed) return fail(BMX_E_STATE, "no scan results: call bmx_ctx_scan after bmx_ctx_set_tests");
+    *d_rec = c->rec.p;
+    return BMX_OK;
+}
+
+int bmx_ctx_fetch_records(bmx_ctx *c, bmx_record *rec) {
+    if (!c || !rec) return fail(BMX_E_INVALID, "NULL argument");
+    if (!c->has_tests || !c->timed) return fail(BMX_E_STATE, "no scan results to fetch");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(rec, c->rec.p, (size_t)c->M * sizeof(bmx_record), hipMemcpyDeviceToHost));
     return BMX_OK;
 }
 
@@ -1617,22 +1902,25 @@ int bmx_ctx_fetch(bmx_ctx *c, double *clr, int32_t *ix, int32_t *ia, int32_t *iA
     HIP_TRY(hipSetDevice(c->device));
     std::vector<int32_t> lin((size_t)c->M);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (clr) HIP_TRY(hipMemcpy(clr, c->d_clr, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost));
-    if (nsites) HIP_TRY(hipMemcpy(nsites, c->d_nsites, (size_t)c->M * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(lin.data(), c->d_lin, (size_t)c->M * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (int64_t t = 0; t < c->M; t++) {
-        int32_t L = lin[(size_t)t];
-        int32_t a = -1, b = -1, d = -1;
-        if (L >= 0) {
-            d = L / c->npairs;
-            int32_t p = L % c->npairs;
-            a = p / c->nab;
-            b = p % c->nab;
+    if (clr) HIP_TRY(hipMemcpy(clr, c->clr.p, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost));
+    if (nsites) HIP_TRY(hipMemcpy(nsites, c->nsites.p, (size_t)c->M * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lin.data(), c->lin.p, (size_t)c->M * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int32_t npairs = c->npairs, nab = c->nab;
+    parallel_ranges(c->M, 1 << 18, [&](int, int64_t b, int64_t e) {
+        for (int64_t t = b; t < e; t++) {
+            const int32_t L = lin[(size_t)t];
+            int32_t a = -1, bb = -1, d = -1;
+            if (L >= 0) {
+                d = L / npairs;
+                const int32_t p = L % npairs;
+                a = p / nab;
+                bb = p % nab;
+            }
+            if (ix) ix[t] = a;
+            if (ia) ia[t] = bb;
+            if (iA) iA[t] = d;
         }
-        if (ix) ix[t] = a;
-        if (ia) ia[t] = b;
-        if (iA) iA[t] = d;
-    }
+    });
     return BMX_OK;
 }
 
@@ -1652,24 +1940,145 @@ int bmx_ctx_surface(bmx_ctx *c, double test_gen, int64_t win_lo, int64_t win_hi,
     if (!c->has_model || !c->has_sites) return fail(BMX_E_STATE, "model and sites must be set before surface");
     HIP_TRY(hipSetDevice(c->device));
     SurfParams S;
-    S.genpos = c->d_genpos; S.row = RowArray{c->d_row, c->d_row32}; S.N = c->N; S.Rt = c->d_Rt; S.NP = c->NP; S.npairs = c->npairs;
+    S.genpos = c->genpos.p; S.row = RowArray{c->wide_rows ? nullptr : c->row16.p, c->wide_rows ? c->row32.p : nullptr}; S.N = c->N; S.Rt = c->d_Rt; S.NP = c->NP; S.npairs = c->npairs;
     S.nslices = c->nslices; S.A = c->d_A; S.nA = c->nA; S.tg = test_gen;
     S.lo = std::max<int64_t>(win_lo, 0); S.hi = std::min<int64_t>(win_hi, c->N - 1); S.zcut = c->zcut;
-    double *dT = nullptr;
-    int32_t *dn = nullptr;
-    HIP_TRY(hipMalloc((void **)&dT, (size_t)c->nA * c->npairs * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&dn, (size_t)c->nA * sizeof(int32_t)));
-    S.T = dT; S.ns = dn;
+    HIP_TRY(c->surf_T.ensure((size_t)c->nA * c->npairs));
+    HIP_TRY(c->surf_ns.ensure((size_t)c->nA));
+    S.T = c->surf_T.p; S.ns = c->surf_ns.p;
     hipLaunchKernelGGL(surface_kernel, dim3((unsigned)(c->nA * c->nslices)), dim3(WAVE), 0, c->stream, S);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(T_out, dT, (size_t)c->nA * c->npairs * sizeof(double), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && nsites_out) e = hipMemcpy(nsites_out, dn, (size_t)c->nA * sizeof(int32_t), hipMemcpyDeviceToHost);
-    (void)hipFree(dT);
-    (void)hipFree(dn);
-    if (e != hipSuccess) return fail(BMX_E_HIP, std::string("surface: ") + hipGetErrorString(e));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(T_out, c->surf_T.p, (size_t)c->nA * c->npairs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (nsites_out) HIP_TRY(hipMemcpyAsync(nsites_out, c->surf_ns.p, (size_t)c->nA * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return BMX_OK;
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------- streaming output
+// The reference writes each row as soon as calcBaller returns it (BalLeRMix+_v1.py:599-608).  Here the test sites are
+// scanned in chunks on the context's stream; chunk i's results travel to pinned host memory on a second stream and are
+// formatted and appended to the output file by a writer thread while chunk i+1 is being scanned.
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+
+extern "C" int bmx_ctx_scan_write(bmx_ctx *c, const char *path, const int64_t *phys, const double *gen,
+                                  const char *xs, int nx, const char *abs_, int nab, const char *As, int nA, int64_t chunk) {
+    if (!c || !path || !phys || !gen || !xs || !abs_ || !As) return fail(BMX_E_INVALID, "NULL argument");
+    if (!c->has_model || !c->has_sites || !c->has_tests) return fail(BMX_E_STATE, "model, sites and tests must be set before scan");
+    if (nx != c->nx || nab != c->nab || nA != c->nA) return fail(BMX_E_INVALID, "printed grids do not match the model's grids");
+    HIP_TRY(hipSetDevice(c->device));
+    ScanPlan pl;
+    int rc = plan_scan(c, pl);
+    if (rc) return rc;
+    if (chunk <= 0) chunk = 65536;
+    chunk = std::min<int64_t>(std::max<int64_t>(chunk / pl.spb, 1) * pl.spb, pl.range);
+    const size_t slot_bytes = (size_t)chunk * 16;
+    if (c->h_stage_cap < slot_bytes) {
+        for (int k = 0; k < 2; k++) {
+            if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
+            c->h_stage[k] = nullptr;
+        }
+        c->h_stage_cap = 0;
+        for (int k = 0; k < 2; k++) HIP_TRY(hipHostMalloc(&c->h_stage[k], slot_bytes, hipHostMallocDefault));
+        c->h_stage_cap = slot_bytes;
+    }
+    bmx_row_tables_ *tabs = bmx_row_tables_new_(xs, nx, abs_, nab, As, nA);
+    FILE *f = fopen(path, "a");
+    if (!f) {
+        bmx_row_tables_free_(tabs);
+        return fail(BMX_E_INVALID, std::string("cannot open ") + path + ": " + strerror(errno));
+    }
+    struct Job { int slot; int64_t off, cnt; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> jobs;
+    bool slot_free[2] = {true, true}, done = false;
+    int werr = 0;                  // 1: event wait failed, 2: formatting/writing failed
+    std::thread writer([&]() {
+        (void)hipSetDevice(c->device);
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !jobs.empty() || done; });
+                if (jobs.empty()) return;
+                j = jobs.front();
+                jobs.pop_front();
+            }
+            int e = 0;
+            if (hipEventSynchronize(c->ev_copied[j.slot]) != hipSuccess) e = 1;
+            if (!e && !werr) {
+                const char *base = (const char *)c->h_stage[j.slot];
+                const double *hclr = (const double *)base;
+                const int32_t *hlin = (const int32_t *)(base + (size_t)chunk * 8);
+                const int32_t *hns = (const int32_t *)(base + (size_t)chunk * 12);
+                if (bmx_write_chunk_(f, tabs, j.cnt, phys + j.off, gen + j.off, hclr, nullptr, nullptr, nullptr, hlin, hns)) e = 2;
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (e && !werr) werr = e;
+                slot_free[j.slot] = true;
+            }
+            cv.notify_all();
+        }
+    });
+    auto finish = [&](int code, const std::string &msg) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            done = true;
+        }
+        cv.notify_all();
+        writer.join();
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->copy_stream);
+        const bool wfail = fclose(f) != 0;
+        bmx_row_tables_free_(tabs);
+        if (code) return fail(code, msg);
+        if (werr == 1) return fail(BMX_E_HIP, "streaming writer: waiting for a result copy failed");
+        if (werr == 2) return fail(BMX_E_INVALID, std::string("streaming writer: ") + bmx_last_error());
+        if (wfail) return fail(BMX_E_INVALID, "write failed");
+        return (int)BMX_OK;
+    };
+#define STREAM_TRY(expr)                                                                                  \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return finish(BMX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+    STREAM_TRY(hipEventRecord(c->ev0, c->stream));
+    int k = 0;
+    for (int64_t off = 0; off < c->M; off += chunk, ++k) {
+        const int64_t cnt = std::min(chunk, c->M - off);
+        const int slot = k & 1;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return slot_free[slot]; });
+            if (werr) break;
+            slot_free[slot] = false;
+        }
+        if ((rc = launch_range(c, pl, off, cnt))) return finish(rc, g_err);
+        STREAM_TRY(hipEventRecord(c->ev_done[slot], c->stream));
+        STREAM_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_done[slot], 0));
+        char *base = (char *)c->h_stage[slot];
+        STREAM_TRY(hipMemcpyAsync(base, c->clr.p + off, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->copy_stream));
+        STREAM_TRY(hipMemcpyAsync(base + (size_t)chunk * 8, c->lin.p + off, (size_t)cnt * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        STREAM_TRY(hipMemcpyAsync(base + (size_t)chunk * 12, c->nsites.p + off, (size_t)cnt * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        STREAM_TRY(hipEventRecord(c->ev_copied[slot], c->copy_stream));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            jobs.push_back(Job{slot, off, cnt});
+        }
+        cv.notify_all();
+    }
+    STREAM_TRY(hipEventRecord(c->ev1, c->stream));
+#undef STREAM_TRY
+    c->timed = true;
+    return finish(BMX_OK, "");
+}
+
+extern "C" {
 
 int bmx_lut_build(const bmx_model *m, double *psel_out, double *R_out, int device) {
     bmx_ctx *c = nullptr;

@@ -3,20 +3,24 @@
 The path has no exchange step: every output row depends only on the
 read-only site arrays around its test site, so each rank holds the full site arrays of
 the chromosome it works on plus the (<1 MB) table, scans its share of the test sites,
-and the 16-byte result records (CLR f64, linear grid index i32, nSites i32) are gathered
-to every rank with one all_gather per array -- RCCL over xGMI when the backend is 'nccl',
-gloo on CPU in the tests.  Results do not depend on the number of ranks: a window is
-always reduced by one workgroup set in the same order.
+and the 16-byte result records (bmx_record: CLR f64, linear grid index i32, nSites i32) go to
+the rank that writes the output with ONE gather -- RCCL over xGMI when the backend is 'nccl'
+(every peer has its own link to rank 0), gloo on CPU in the tests.  Results do not depend on
+the number of ranks: a window is always reduced by one workgroup set in the same order.
 """
 import os
 
 import numpy as np
 
-BLOCK = 4096   # test sites are dealt to ranks in blocks of this many (balances density changes)
+BLOCK = 4096   # test sites are dealt to ranks in blocks of this many (balances density changes; a multiple of the
+               # kernel's group size, so no window's arithmetic depends on the number of ranks)
+RECORD = np.dtype([('clr', '<f8'), ('lin', '<i4'), ('nsites', '<i4')])     # bmx_record, include/bmxscan.h
 
 
-def assign(M, world, block=BLOCK):
-    """Index arrays, one per rank: blocks of `block` consecutive test sites dealt round-robin."""
+def assign(M, world, block=None):
+    """Index arrays, one per rank: blocks of `block` (default: BLOCK, read at call time) consecutive
+    test sites dealt round-robin."""
+    block = BLOCK if block is None else int(block)
     nblk = (M + block - 1) // block
     out = []
     for r in range(world):
@@ -36,6 +40,8 @@ class _DevArray:
 class World:
     def __init__(self, rank=0, size=1, local_rank=0, backend=None):
         self.rank, self.size, self.local_rank, self.backend = rank, size, local_rank, backend
+        # the GPU this rank computes on: LOCAL_RANK, or 0 for every rank when several ranks rehearse on ONE GPU
+        self.device_index = 0 if os.environ.get('BMX_SINGLE_DEVICE') == '1' else local_rank
         self._own_pg = False
         self.force = False
 
@@ -55,7 +61,7 @@ class World:
                 backend = 'nccl' if torch.cuda.is_available() else 'gloo'
             w.backend = backend
             if backend == 'nccl':
-                torch.cuda.set_device(local)
+                torch.cuda.set_device(w.device_index)
             if not dist.is_initialized():
                 os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
                 os.environ.setdefault('MASTER_PORT', '29533')
@@ -75,34 +81,33 @@ class World:
                 dist.destroy_process_group()
 
     # ------------------------------------------------------------------ gather
-    def all_gather_records(self, clr, lin, ns, counts):
-        """Gather per-rank (clr f64, lin i32, ns i32) arrays of lengths `counts` to every rank.
-        Inputs are numpy arrays (gloo) or torch CUDA tensors (nccl); returns numpy arrays per rank."""
+    def gather_records(self, rec, counts, dst=0):
+        """ONE gather of 16-byte records to rank `dst`.  `rec`: this rank's records, either a numpy structured
+        array (RECORD) or a torch int64 tensor of shape [n, 2] (a zero-copy view of the library's device records
+        for the nccl backend).  Returns a list of RECORD arrays, one per rank, on `dst`; None elsewhere."""
         import torch
         import torch.distributed as dist
         pad = max(counts) if counts else 0
-        dev = torch.device('cuda', self.local_rank) if self.backend == 'nccl' else torch.device('cpu')
-
-        def prep(a, dtype):
-            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
-            t = t.to(device=dev, dtype=dtype)
-            if t.numel() < pad:
-                t = torch.cat([t, torch.zeros(pad - t.numel(), dtype=dtype, device=dev)])
-            return t.contiguous()
-
-        outs = []
-        for a, dtype in ((clr, torch.float64), (lin, torch.int32), (ns, torch.int32)):
-            mine = prep(a, dtype)
-            buf = torch.empty(pad * self.size, dtype=dtype, device=dev)
-            dist.all_gather_into_tensor(buf, mine)
-            outs.append(buf.cpu().numpy().reshape(self.size, pad))
-        return [[o[r, :counts[r]] for r in range(self.size)] for o in outs]
+        dev = torch.device('cuda', self.device_index) if self.backend == 'nccl' else torch.device('cpu')
+        if isinstance(rec, torch.Tensor):
+            t = rec.reshape(-1, 2)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(rec, dtype=RECORD).view(np.int64).reshape(-1, 2))
+        t = t.to(device=dev)
+        if t.shape[0] < pad:
+            t = torch.cat([t, torch.zeros((pad - t.shape[0], 2), dtype=torch.int64, device=dev)])
+        t = t.contiguous()
+        bufs = [torch.empty((pad, 2), dtype=torch.int64, device=dev) for _ in range(self.size)] if self.rank == dst else None
+        dist.gather(t, bufs, dst=dst)
+        if self.rank != dst:
+            return None
+        return [b.cpu().numpy().view(RECORD).reshape(-1)[:counts[r]] for r, b in enumerate(bufs)]
 
     # ------------------------------------------------------------------ runner
-    def sharded_runner(self, compute=None):
-        """A drop-in for engine.scan_batch that scans only this rank's test sites and
-        all-gathers the records.  `compute(sel, test_gen, lo, hi) -> (clr, lin, ns)` defaults to
-        the GPU scan; tests inject a CPU function to exercise the sharding on gloo."""
+    def sharded_runner(self, compute=None, block=None):
+        """A drop-in for engine.scan_batch that scans only this rank's test sites and gathers the records on
+        rank 0; the other ranks get None back (they write nothing).  `compute(sel, test_gen, lo, hi) -> (clr, lin, ns)`
+        defaults to the GPU scan; tests inject a CPU function to exercise the sharding on gloo."""
         world = self
 
         def run(sel, test_gen, win_lo, win_hi):
@@ -110,38 +115,32 @@ class World:
             win_lo = np.asarray(win_lo, dtype=np.int64)
             win_hi = np.asarray(win_hi, dtype=np.int64)
             M = len(test_gen)
-            parts = assign(M, world.size)
+            parts = assign(M, world.size, block)
             mine = parts[world.rank]
             counts = [len(p) for p in parts]
             if compute is not None:
                 clr, lin, ns = compute(sel, test_gen[mine], win_lo[mine], win_hi[mine])
+                rec = np.empty(len(mine), dtype=RECORD)
+                rec['clr'], rec['lin'], rec['nsites'] = clr, lin, ns
             elif len(mine):
-                import torch
                 sel.ctx.set_tests(test_gen[mine], win_lo[mine], win_hi[mine])
                 sel.ctx.scan()
                 sel.ctx.sync()
                 if world.backend == 'nccl':
-                    pc, pl, pn = sel.ctx.result_ptrs()
-                    dev = torch.device('cuda', world.local_rank)
-                    clr = torch.as_tensor(_DevArray(pc, len(mine), '<f8'), device=dev)
-                    lin = torch.as_tensor(_DevArray(pl, len(mine), '<i4'), device=dev)
-                    ns = torch.as_tensor(_DevArray(pn, len(mine), '<i4'), device=dev)
+                    import torch
+                    rec = torch.as_tensor(_DevArray(sel.ctx.records(), 2 * len(mine), '<i8'),
+                                          device=torch.device('cuda', world.device_index))
                 else:
-                    c, ix, ia, iA, n = sel.ctx.fetch()
-                    npairs = len(sel.grid_x) * len(sel.grid_abeta)
-                    clr, ns = c, n
-                    lin = np.where(iA < 0, -1, iA * npairs + ix * len(sel.grid_abeta) + ia).astype(np.int32)
+                    rec = sel.ctx.fetch_records()
             else:
-                clr, lin, ns = np.zeros(0), np.zeros(0, np.int32), np.zeros(0, np.int32)
-            g_clr, g_lin, g_ns = world.all_gather_records(clr, lin, ns, counts)
-            clr_all = np.empty(M, dtype=np.float64)
-            lin_all = np.empty(M, dtype=np.int32)
-            ns_all = np.empty(M, dtype=np.int32)
+                rec = np.zeros(0, dtype=RECORD)
+            got = world.gather_records(rec, counts)
+            if got is None:
+                return None
+            out = np.empty(M, dtype=RECORD)
             for r in range(world.size):
-                clr_all[parts[r]] = g_clr[r]
-                lin_all[parts[r]] = g_lin[r]
-                ns_all[parts[r]] = g_ns[r]
-            return unpack_lin(clr_all, lin_all, ns_all, len(sel.grid_x), len(sel.grid_abeta))
+                out[parts[r]] = got[r]
+            return unpack_lin(out['clr'].copy(), out['lin'], out['nsites'].copy(), len(sel.grid_x), len(sel.grid_abeta))
 
         return run
 

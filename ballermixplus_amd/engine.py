@@ -125,6 +125,28 @@ class Context:
         _lib.check(self._L.bmx_ctx_result_ptrs(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def records(self):
+        """Device address of the M 16-byte result records (bmx_record) of the last scan."""
+        a = C.c_void_p()
+        _lib.check(self._L.bmx_ctx_records(self._h, C.byref(a)))
+        return a.value
+
+    def fetch_records(self):
+        """The last scan's results as a structured array (clr f8, lin i4, nsites i4)."""
+        rec = np.empty(self.M, dtype=_lib.RECORD_DTYPE)
+        _lib.check(self._L.bmx_ctx_fetch_records(self._h, rec.ctypes.data_as(C.c_void_p)))
+        return rec
+
+    def scan_write(self, path, phys, gen_label, xs, abs_, As, chunk=0):
+        """Scan the test sites set by set_tests and append the reference's rows to `path` while scanning
+        (chunks of test sites; a writer thread formats chunk i while chunk i+1 is on the device)."""
+        phys, gen_label = _lib.i64(phys), _lib.f64(gen_label)
+        if len(phys) != self.M or len(gen_label) != self.M:
+            raise ValueError('one (physPos, genPos) label pair per test site is needed')
+        pack = lambda v: b'\0'.join(s.encode() for s in v) + b'\0'
+        _lib.check(self._L.bmx_ctx_scan_write(self._h, path.encode(), _lib.as_lp(phys), _lib.as_dp(gen_label), pack(xs), len(xs),
+                                              pack(abs_), len(abs_), pack(As), len(As), int(chunk)))
+
     def surface(self, test_gen, win_lo, win_hi):
         """T[nA, nx, nab] (NaN where the window is empty) and nsites[nA] of one test site."""
         m = self.model
@@ -192,6 +214,15 @@ class NormalizedBetaBinom:
             self._psel, _ = self.ctx.fetch_lut()
         i, j = self._key[(x, a)]
         return self._psel[i, j][self.rows]
+
+
+def scan_stream(sel, test_gen, win_lo, win_hi, outfile, phys, gen_label):
+    """scan_batch + the output rows appended to `outfile` while the scan runs (the reference writes as it scans,
+    v1:599-608).  Returns what scan_batch returns."""
+    sel.ctx.set_tests(test_gen, win_lo, win_hi)
+    sel.ctx.scan_write(outfile, phys, gen_label, [f'{v}' for v in sel.grid_x], [f'{v}' for v in sel.grid_abeta],
+                       [f'{v}' for v in sel.grid_A])
+    return sel.ctx.fetch()
 
 
 def scan_batch(sel, test_gen, win_lo, win_hi):

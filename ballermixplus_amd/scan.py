@@ -237,33 +237,43 @@ class Scan:
     """v1:510-640: same constructor, same dispatch, same messages."""
 
     def __init__(self, InputData, NeutralSFS, NormalizedBetaBinom, Grids, outfile, fixSize=False, r=0, s=1,
-                 phys=False, noCenter=False, runner=None):
+                 phys=False, noCenter=False, runner=None, verbose=True):
+        # verbose=False: the ranks of a multi-GPU run that do not write the output stay silent
+        say = print if verbose else (lambda *a, **k: None)
         if fixSize:
-            print('You\'ve chosen to fix the size (in nt) of sliding window for scanning.')
+            say('You\'ve chosen to fix the size (in nt) of sliding window for scanning.')
             if r == 0:
-                print('Please set a window width in nt with "-w" or "--window" command.')
+                say('Please set a window width in nt with "-w" or "--window" command.')
                 sys.exit()
             if not phys:
-                print(f'Please make sure to use physical positions as coordinates if fixed-length windows are chosen (--fixSize). Scan will continue with physical positions with a rec rate of {InputData.Rrate} cM/nt.')
+                say(f'Please make sure to use physical positions as coordinates if fixed-length windows are chosen (--fixSize). Scan will continue with physical positions with a rec rate of {InputData.Rrate} cM/nt.')
                 phys = True
             w = float(r)
             if noCenter:
-                print(('Computing LR on %.3f kb windows on every %s nt. Using physical positions by default.' % (w / 1e3, s)))
+                say(('Computing LR on %.3f kb windows on every %s nt. Using physical positions by default.' % (w / 1e3, s)))
                 ts = sites_fix_nocenter(InputData, w, s)
             else:
-                print(('Computing LR on %.3f kb windows on every %g informative sites. Using physical positions by default.' % (w / 1e3, s)))
+                say(('Computing LR on %.3f kb windows on every %g informative sites. Using physical positions by default.' % (w / 1e3, s)))
                 ts = sites_fix_center(InputData, w, s)
         elif r != 0:
-            print(('Computing LR on every %s site/s, with a radius of %g informative sites on either side.' % (s, r)))
+            say(('Computing LR on every %s site/s, with a radius of %g informative sites on either side.' % (s, r)))
             ts = sites_site_based(InputData, r, s)
         else:
-            print(('Computing LR on every %s site/s, using informative sites with exp(-A*dist) >= 1e-8.' % (s)))
+            say(('Computing LR on every %s site/s, using informative sites with exp(-A*dist) >= 1e-8.' % (s)))
             ts = sites_alpha(InputData, s)
-        print(("writing output to %s" % (outfile)))
+        say(("writing output to %s" % (outfile)))
         NormalizedBetaBinom.bind(NeutralSFS)
         run = runner or engine.scan_batch
+        streamed = False
         if len(ts):
-            if ts.arrays is not None:
+            if runner is None and outfile is not None and ts.arrays is not None and not ts.na_rows:
+                # one GPU, plain index-stride test sites (integer physPos): rows are written while the scan runs
+                with open(outfile, 'w') as scores:
+                    scores.write(HEADER)
+                results = engine.scan_stream(NormalizedBetaBinom, ts.arrays[1], ts.arrays[2], ts.arrays[3], outfile,
+                                             ts.arrays[0], ts.arrays[1])
+                streamed = True
+            elif ts.arrays is not None:
                 results = run(NormalizedBetaBinom, ts.arrays[1], ts.arrays[2], ts.arrays[3])
             else:
                 results = run(NormalizedBetaBinom, ts.test_gen, ts.lo, ts.hi)
@@ -271,6 +281,6 @@ class Scan:
             results = (np.zeros(0), np.zeros(0, int), np.zeros(0, int), np.zeros(0, int), np.zeros(0, int))
         self.test_sites = ts
         self.results = results
-        if outfile is not None and results is not None:
+        if outfile is not None and results is not None and not streamed:
             write_rows(outfile, ts, results, NormalizedBetaBinom)
-        print(f'{datetime.now()}. Scan finished.')
+        say(f'{datetime.now()}. Scan finished.')

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define BMX_ABI_VERSION_MAJOR 1
-#define BMX_ABI_VERSION_MINOR 0
+#define BMX_ABI_VERSION_MINOR 1
 
 enum {
     BMX_OK = 0,
@@ -67,8 +67,20 @@ typedef struct bmx_model {
     const double *abeta;     /* [nab]  (v1:474) */
 } bmx_model;
 
+/* One result row as the multi-GPU gather moves it (16 bytes): CLR, linear grid index
+ * (iA*nx + ix)*nab + ia (-1: no grid point had T > 0) and nSites -- Tmax[0], Tmax[1:4], Tmax[4] of
+ * calcBaller's return value (BalLeRMix+_v1.py:451,502,507). */
+typedef struct bmx_record {
+    double clr;
+    int32_t lin;
+    int32_t nsites;
+} bmx_record;
+
 /* ---- library-level queries -------------------------------------------------------- */
 void bmx_version(int *major, int *minor);
+/* Hash of the kernel/host sources this binary was built from (first 16 hex digits of their SHA-256, set by the
+ * Makefile): the Python shim refuses a library whose id differs from the sources next to it. */
+const char *bmx_build_id(void);
 const char *bmx_last_error(void);
 /* Number of visible HIP devices (0 when none / no driver). */
 int bmx_device_count(void);
@@ -129,6 +141,18 @@ int bmx_ctx_fetch(bmx_ctx *c, double *clr, int32_t *ix, int32_t *ia, int32_t *iA
  * (iA*nx + ix)*nab + ia, or -1), nsites i32[M].  Valid until the next set_tests/destroy;
  * used for the RCCL gather without a host round trip. */
 int bmx_ctx_result_ptrs(bmx_ctx *c, void **d_clr, void **d_lin, void **d_nsites);
+/* The same results as one array of M bmx_record: device address (for a single RCCL gather to the
+ * writing rank) and host copy.  Valid until the next set_tests/destroy. */
+int bmx_ctx_records(bmx_ctx *c, void **d_rec);
+int bmx_ctx_fetch_records(bmx_ctx *c, bmx_record *rec);
+/* Scan and stream: the rows of `scores.write(...)` (BalLeRMix+_v1.py:599-608) are appended to `path`
+ * while the scan is still running.  Test sites go to the device `chunk` at a time (0: 65536; rounded to
+ * whole workgroups, which keeps every result bit-identical to bmx_ctx_scan); each chunk's results are copied
+ * to pinned host memory on a second stream and formatted/written by a host thread while the next chunk is
+ * scanned.  phys[M], gen[M]: the first two columns of each row; xs/abs_/As: the grids' printed forms as for
+ * bmx_write_rows (they must have the model's nx/nab/nA entries).  Results stay fetchable afterwards. */
+int bmx_ctx_scan_write(bmx_ctx *c, const char *path, const int64_t *phys, const double *gen,
+                       const char *xs, int nx, const char *abs_, int nab, const char *As, int nA, int64_t chunk);
 /* Copy the resident tables back: psel/R as in bmx_lut_build (either may be NULL). */
 int bmx_ctx_fetch_lut(bmx_ctx *c, double *psel_out, double *R_out);
 /* Full likelihood surface of ONE test site: T_out[nA][nx][nab] = T(A, x, alpha_beta) in the grids'

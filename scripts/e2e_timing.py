@@ -32,3 +32,26 @@ for rep in range(2):
     dt = time.time() - t
 print('host buffers in -> host buffers out (H2D + locate + scan + D2H): %.3f s = %.0f windows/s; scan kernel alone %.1f ms'
       % (dt, N / dt, ctx.last_scan_ms()))
+
+# the CLI's stages in this process, timed one by one (imports done, GPU context warm)
+import hashlib
+from ballermixplus_amd.hostmodel import InputData, NeutralSFS
+from ballermixplus_amd import scan as scanmod
+import io, contextlib
+quiet = io.StringIO()
+with contextlib.redirect_stdout(quiet):
+    t0 = time.time(); data = InputData(inp, False, False, False, 1, phys=False, Rrate=1e-6); t1 = time.time()
+    neut = NeutralSFS(spect, False, False, False); neut.get_neut_probs(data); t2 = time.time()
+    sel = engine.NormalizedBetaBinom(data, grid, False, False, False, device=0).bind(neut); t3 = time.time()
+    out2 = '/tmp/bmx_e2e_out2.txt'
+    scanmod.Scan(data, neut, sel, grid, out2); t4 = time.time()
+    # the batch path (scan everything, fetch, then format and write) for comparison
+    out3 = '/tmp/bmx_e2e_out3.txt'
+    ts = scanmod.sites_alpha(data, 1)
+    t5 = time.time()
+    res = engine.scan_batch(sel, ts.arrays[1], ts.arrays[2], ts.arrays[3]); t6 = time.time()
+    scanmod.write_rows(out3, ts, res, sel); t7 = time.time()
+print('stages (s): parse %.3f | neutral model %.3f | K1 + site upload %.3f | streamed scan+write %.3f (kernel %.3f) || batch: scan+fetch %.3f, format+write %.3f'
+      % (t1 - t0, t2 - t1, t3 - t2, t4 - t3, sel.ctx.last_scan_ms() / 1e3, t6 - t5, t7 - t6))
+md5 = lambda p: hashlib.md5(open(p, 'rb').read()).hexdigest()
+print('output files identical (CLI / streamed / batch):', md5(out) == md5(out2) == md5(out3), md5(out))

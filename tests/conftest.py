@@ -10,11 +10,23 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    # the in-tree library is git-ignored: build it if a fresh checkout has not run build() yet
-    so = os.path.join(REPO, 'ballermixplus_amd', 'libbmxscan.so')
-    if not os.path.exists(so):
-        import subprocess
-        subprocess.run(['make', '-C', os.path.join(REPO, 'ballermixplus_amd', 'csrc')], check=False,
+    # The in-tree library is git-ignored and travels to the GPU box as a binary: (re)build it whenever it is missing
+    # or was built from other sources than the ones in the tree (bmx_build_id vs the sources' hash), so that a stale
+    # binary is never what gets tested.  `make` is incremental; _lib.lib() raises if the ids still differ.
+    import ctypes
+    import subprocess
+    from ballermixplus_amd import _lib
+    so = _lib.LIB_PATH
+    stale = True
+    if os.path.exists(so):
+        try:
+            L = ctypes.CDLL(so)
+            L.bmx_build_id.restype = ctypes.c_char_p
+            stale = L.bmx_build_id().decode() != _lib.source_id()
+        except (OSError, AttributeError):
+            stale = True
+    if stale:
+        subprocess.run(['make', '-B', '-C', os.path.join(REPO, 'ballermixplus_amd', 'csrc')], check=False,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 

@@ -1,6 +1,7 @@
-"""The N>1 path on CPU: world_size 2 over gloo.  The GPU scan is replaced by the C oracle as the
-per-rank compute function; what is under test is the sharding (blocks of 4096 test sites dealt
-round-robin), the all_gather of the (CLR, linear index, nSites) records and the reassembly."""
+"""The N>1 path on CPU: world_size 2 (and 3) over gloo.  The GPU scan is replaced by the C oracle as the
+per-rank compute function; what is under test is the sharding (blocks of test sites dealt round-robin,
+with a partial last block), the single gather of the 16-byte (CLR, linear index, nSites) records to rank 0
+and the reassembly."""
 import os
 import socket
 import sys
@@ -42,20 +43,32 @@ def _worker(rank, world, port, q):
     class Sel:
         grid_x, grid_abeta = case.xs, case.abetas
 
-    distributed.BLOCK = 64            # 757 test sites -> 12 blocks, dealt 6/6
-    run = w.sharded_runner(compute=compute)
+    # 757 test sites in blocks of 64 -> 11 full blocks + one of 53, dealt round-robin: every rank scans something
+    parts = distributed.assign(len(ts.test_gen), world, 64)
+    assert all(len(p) > 0 for p in parts) and sum(len(p) for p in parts) == 757 and len(parts[11 % world]) % 64 == 53
+    seen = []
+
+    def counting(sel, tg, lo, hi):
+        seen.append(len(tg))
+        return compute(sel, tg, lo, hi)
+
+    run = w.sharded_runner(compute=counting, block=64)
     res = run(Sel, ts.test_gen, ts.lo, ts.hi)
+    assert seen == [len(parts[rank])]
     if rank == 0:
         q.put([np.asarray(a) for a in res])
+    else:
+        assert res is None                 # only the writing rank holds the gathered rows
     w.finish()
 
 
-def test_two_rank_sharded_scan_equals_single_process():
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_scan_equals_single_process(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)
@@ -81,6 +94,26 @@ def test_assignment_covers_every_test_site_once():
         assert len(allidx) == M and np.array_equal(np.sort(allidx), np.arange(M))
         for p in parts:          # every shard starts on a multiple of the kernel's group size
             assert len(p) == 0 or all(int(b) % 16 == 0 for b in p[::distributed.BLOCK][:4])
+    # the block size is read when assign() is CALLED (a default argument would have frozen 4096 at import)
+    old = distributed.BLOCK
+    try:
+        distributed.BLOCK = 64
+        assert [len(p) for p in distributed.assign(757, 2)] == [6 * 64, 5 * 64 + 53]
+    finally:
+        distributed.BLOCK = old
+    assert [len(p) for p in distributed.assign(757, 2)] == [757, 0]
+
+
+def test_record_gather_layout():
+    """The 16-byte record is (f64, i32, i32) in that order: the int64-pair view used on the wire round-trips."""
+    from ballermixplus_amd import _lib, distributed
+    assert distributed.RECORD.itemsize == 16 and distributed.RECORD == _lib.RECORD_DTYPE
+    import ctypes as C
+    assert C.sizeof(_lib.BmxRecord) == 16
+    rec = np.zeros(3, dtype=distributed.RECORD)
+    rec['clr'], rec['lin'], rec['nsites'] = [1.5, 0.0, 7.25], [3, -1, 15809], [10, 0, 5000]
+    back = rec.view(np.int64).reshape(-1, 2).copy().view(distributed.RECORD).reshape(-1)
+    assert np.array_equal(back, rec)
 
 
 def test_unpack_lin_roundtrip():

@@ -165,6 +165,34 @@ def test_native_reader_edge_cases(tmp_path):
         _lib.read_input(str(f), 1)
     with pytest.raises(_lib.BmxError):
         _lib.read_input(str(tmp_path / 'missing.txt'), 1)
+    # an empty last column must not take its value from the next line (strtoll skips '\n'); hex floats, inf and
+    # fields with leading blanks are left to the Python reader, which reproduces the reference's behaviour
+    for body in ('100\t0.1\t5\t\n200\t0.2\t3\t50\n', '100\t0.1\t\t50\n', '0x10\t0.1\t5\t50\n', 'inf\t0.1\t5\t50\n',
+                 '100\t 0.1\t5\t50\n', '100\t0.1\t5.0\t50\n', '100\t0.1\t5\t50junk\n'):
+        f.write_text('physPos\tgenPos\tx\tn\n' + body)
+        with pytest.raises(_lib.BmxError):
+            _lib.read_input(str(f), 1)
+
+
+def test_native_reader_threads_agree_with_one_range(tmp_path):
+    """Files beyond 1 MB are cut into one byte range per thread at line boundaries: same arrays as line by line."""
+    from ballermixplus_amd import _lib, synth
+    phys, gen, k, n = synth.synth_chromosome(120000, 100, 7)
+    f = tmp_path / 'big.txt'
+    synth.write_input(str(f), phys, gen, k, n)
+    assert f.stat().st_size > 2 << 20
+    ph, co, kk, nn = _lib.read_input(str(f), 1)
+    assert np.array_equal(ph, phys) and np.array_equal(kk, k) and np.array_equal(nn, n)
+    assert np.array_equal(co, np.array([float('%.6f' % g) for g in gen]))
+    with open(f, 'rb+') as fh:                      # no final newline, and a malformed line deep in the file
+        fh.seek(-1, 2)
+        fh.truncate()
+    assert np.array_equal(_lib.read_input(str(f), 0)[0], phys)
+    lines = f.read_text().split('\n')
+    lines[90001] = lines[90001].replace('\t', ' ', 1)
+    f.write_text('\n'.join(lines))
+    with pytest.raises(_lib.BmxError, match='line 90001'):
+        _lib.read_input(str(f), 1)
 
 
 def test_native_float_formatting_equals_python_repr():
