@@ -113,7 +113,13 @@ def main(argv=None):
     say('\n \t A= ' + ', '.join([str(A) for A in grid.A]))
     Sel_Probs = engine.NormalizedBetaBinom(data, grid, opt.nofreq, opt.MAF, opt.nosub, device=device)
     say(("\n%s. Start computing likelihood ratios..." % (datetime.now())))
-    runner = world.sharded_runner() if world.distributed else None
+    # BMX_SHARD_BLOCK: test sites per shard block (default distributed.BLOCK = 4096; a multiple of 16 keeps every window's
+    # arithmetic independent of the number of ranks) -- lets small inputs exercise real sharding in the tests
+    block = int(os.environ['BMX_SHARD_BLOCK']) if os.environ.get('BMX_SHARD_BLOCK') else None
+    if block is not None and (block < 16 or block % 16):
+        print('BMX_SHARD_BLOCK must be a positive multiple of 16.')
+        sys.exit(1)
+    runner = world.sharded_runner(block=block) if world.distributed else None
     Scan(data, Neutral, Sel_Probs, grid, opt.outfile if world.rank == 0 else None, fixSize=opt.size, r=opt.w,
          s=opt.step, phys=opt.phys, noCenter=opt.noCenter, runner=runner, verbose=verbose)
     world.finish()

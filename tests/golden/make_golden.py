@@ -13,6 +13,8 @@ outputs) next to this script.
     python tests/golden/make_golden.py helpers    # --getSpect / --getConfig outputs
     python tests/golden/make_golden.py e2e NAME   # whole-CLI runs (slow, minutes..)
     python tests/golden/make_golden.py synth      # synthetic 20k / 1M strided windows
+    python tests/golden/make_golden.py config4 21 22   # BASELINE config 4: chromosomes of the 40M-SNP genome, -s 50000
+    python tests/golden/make_golden.py config5 1 2     # BASELINE config 5: contigs of 1.25M SNPs, n=200, 100x10x44 grid
 """
 import importlib.util
 import json
@@ -268,6 +270,67 @@ def cmd_synth(which):
             f.write('\n'.join(rows) + '\n')
 
 
+def _strided_reference_run(ref, tag, phys, gen, k, nn, spect_rows, grid, step, out_path):
+    """One chromosome through the reference's own classes, every step-th site, with the helper file of the whole
+    configuration (spect_rows: the --getSpect table of the concatenated input)."""
+    inp = '/tmp/bmx_%s.txt' % tag
+    spectf = '/tmp/bmx_%s_spect.txt' % tag
+    from ballermixplus_amd import synth
+    synth.write_input(inp, phys, gen, k, nn)
+    with open(spectf, 'w') as f:                       # the format getSpect writes (v1:699-708): k n fraction
+        for a, b, fr in spect_rows:
+            f.write('%s\t%s\t%s\n' % (a, b, fr))
+    data = ref.InputData(inp, False, False, False, 1)
+    neut = ref.NeutralSFS(spectf, False, False, False)
+    neut.get_neut_probs(data)
+    t0 = time.time()
+    nb = ref.NormalizedBetaBinom(data, grid, False, False, False)
+    print(tag, 'NormalizedBetaBinom %.0fs' % (time.time() - t0), flush=True)
+    rows = []
+    allidx = np.arange(data.numSites, dtype=int)
+    for i in range(0, data.numSites, step):
+        t0 = time.time()
+        r = ref.calcBaller(allidx, data.genPos[i], data, neut, nb, grid)
+        rows.append(f'{data.position[i]}\t{data.genPos[i]}\t{r[0]}\t{r[1]}\t{r[2]}\t{r[3]}\t{r[4]}')
+        print(tag, i, rows[-1], '%.1fs' % (time.time() - t0), flush=True)
+    with open(out_path, 'w') as f:
+        f.write('physPos\tgenPos\tCLR\tx_hat\ts_hat\tA_hat\tnSites\n')
+        f.write('\n'.join(rows) + '\n')
+    os.remove(inp)
+
+
+def cmd_config4(chroms, step=50000):
+    """BASELINE config 4: 22 chromosomes, 40M SNPs, n=100; the helper file is --getSpect of the concatenation
+    of all 22.  The reference scans the requested chromosomes with -s 50000 (it needs ~5 min and ~8 GB per chromosome of
+    ~700k SNPs; chr1's 3.46M are out of its reach)."""
+    from ballermixplus_amd import synth
+    ref = load_ref()
+    sizes = synth.config4_sizes(40_000_000)
+    data = [synth.synth_chromosome(N, 100, c + 1) for c, N in enumerate(sizes)]
+    spect_rows = synth.spect_from_counts(np.concatenate([d[2] for d in data]), np.concatenate([d[3] for d in data]))
+    outdir = os.path.join(HERE, 'synth')
+    for c in chroms:
+        phys, gen, k, nn = data[c - 1]
+        _strided_reference_run(ref, 'cfg4_chr%d' % c, phys, gen, k, nn, spect_rows, grid_of(ref, 'default'), step,
+                               os.path.join(outdir, 'config4_chr%d_step%d.tsv' % (c, step)))
+
+
+def cmd_config5(contigs, step=125000):
+    """BASELINE config 5: 8 contigs of 1.25M SNPs, n=200, A = 100..10000 step 100 (--listA: the reference's --rangeA
+    raises), --findBal --findPos; helper file from the concatenation of the 8 contigs."""
+    from ballermixplus_amd import synth
+    ref = load_ref()
+    data = [synth.synth_chromosome(1250000, 200, c + 1) for c in range(8)]
+    spect_rows = synth.spect_from_counts(np.concatenate([d[2] for d in data]), np.concatenate([d[3] for d in data]))
+    listA = ','.join(str(100 * i) for i in range(1, 101))
+    grid = ref.Grids(None, None, True, True, None, listA)
+    outdir = os.path.join(HERE, 'synth')
+    for c in contigs:
+        phys, gen, k, nn = data[c - 1]
+        _strided_reference_run(ref, 'cfg5_contig%d' % c, phys, gen, k, nn, spect_rows, grid, step,
+                               os.path.join(outdir, 'config5_contig%d_step%d.tsv' % (c, step)))
+
+
 if __name__ == '__main__':
     cmd = sys.argv[1]
     if cmd == 'lut':
@@ -282,5 +345,9 @@ if __name__ == '__main__':
         cmd_e2e(sys.argv[2:] or list(E2E))
     elif cmd == 'synth':
         cmd_synth(sys.argv[2:] or ['20k'])
+    elif cmd == 'config4':
+        cmd_config4([int(v) for v in sys.argv[2:]] or [21, 22])
+    elif cmd == 'config5':
+        cmd_config5([int(v) for v in sys.argv[2:]] or [1, 2])
     else:
         raise SystemExit(__doc__)

@@ -668,27 +668,3 @@ def test_grouped_kernel_at_config3_scale_against_the_reference():
         assert (repr(xs[ix[j]]), repr(ab[ia[j]]), repr(As[iA[j]]), str(ns[j])) == (r[3], r[4], r[5], r[6]), (j, r)
         assert abs(clr[j] - float(r[2])) <= max(1e-9, 1e-6 * abs(float(r[2]))), (j, r, clr[j])
     ctx.close()
-
-
-def test_bench_contract_two_ranks_on_one_gpu(tmp_path):
-    """bench.py under torch.distributed.run with two ranks sharing this box's one GPU (gloo gather through the
-    host instead of RCCL): exit code 0, exactly ONE JSON line on stdout, whole-job value over both ranks."""
-    import json
-    import subprocess
-    import sys
-    from util import REPO
-    env = dict(os.environ, BMX_DIST_BACKEND='gloo', BMX_SINGLE_DEVICE='1')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', '29617', os.path.join(REPO, 'bench.py'),
-                        '--gpus', '2', '--steps', '1', '--warmup', '1', '--snps', '64000'],
-                       capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['steps'] == 1 and d['warmup'] == 1 and d['scaling'] == 'weak'
-    assert d['unit'] == 'windows/s' and d['higher_is_better'] is True and d['vs_baseline'] is None
-    assert abs(d['value'] - 2 * 64000 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
-    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
-        assert k in d['roofline']
-    assert 'cpu_baseline' not in d            # reported at N = 1 only
