@@ -95,8 +95,11 @@ constexpr int FAR_ORDER = BMX_FAR_ORDER;      // ... to this power of alpha*R (l
 #define BMX_MOM_COPIES 8
 #endif
 constexpr int MOM_COPIES = BMX_MOM_COPIES;                 // copies of the most frequent row's moments (lane % 8): fewer LDS conflicts
+#ifndef BMX_QSB
+#define BMX_QSB 8
+#endif
 #ifndef BMX_FOLD_BATCH
-#define BMX_FOLD_BATCH 4
+#define BMX_FOLD_BATCH 2
 #endif
 constexpr int MID_CAP = 32;                   // grouped kernel: sites between the test sites of a group staged in LDS (12 B each)
 constexpr int FAR_CAP = 8192;                 // ... at most this many sites per zone (exponent budget: 8192 * 0.05 * 1.49 bits < 1000)
@@ -133,7 +136,7 @@ struct LutParams {
 // (v1:399-433), each for b(x) and b(1-x).  All of them go through ONE inlined pmf call site
 // inside nested loops: the pmf body is large, and gfx950 device-function calls from a partially
 // active wave proved unusable here (hang), so nothing in this kernel is an out-of-line call.
-__global__ void bb_lut_kernel(LutParams P) {
+__global__ __launch_bounds__(128) void bb_lut_kernel(LutParams P) {   // 128 threads per workgroup: room for 512 registers, no scratch
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int npairs = P.nx * P.nab;
     if (gid >= (int64_t)npairs * P.rows) return;
@@ -301,6 +304,34 @@ __device__ __forceinline__ double exp_neg(double z) {
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return ldexp(p, (int)n);
+}
+
+// Two independent exp_neg chains, written out interleaved: a chain of 19 dependent FP64 operations runs at the FP64
+// latency (~10 cycles per step for a wave on its own), two interleaved chains at nearly the issue rate.  Used where exps
+// come in batches (the far-field flush: one per test site).
+__device__ __forceinline__ void exp_neg2(double z0, double z1, double &o0, double &o1) {
+    const double t0 = -z0, t1 = -z1;
+    const double n0 = rint(t0 * 1.4426950408889634), n1 = rint(t1 * 1.4426950408889634);
+    double r0 = fma(-n0, 0.6931471805599453, t0), r1 = fma(-n1, 0.6931471805599453, t1);
+    r0 = fma(-n0, 2.3190468138462996e-17, r0);
+    r1 = fma(-n1, 2.3190468138462996e-17, r1);
+    double p0 = fma_sc(1.6059043836821613e-10, r0, 2.08767569878681e-09), p1 = fma_sc(1.6059043836821613e-10, r1, 2.08767569878681e-09);
+#define BMX_STEP2(c) p0 = fma_sc(p0, r0, c); p1 = fma_sc(p1, r1, c);
+    BMX_STEP2(2.505210838544172e-08)
+    BMX_STEP2(2.755731922398589e-07)
+    BMX_STEP2(2.7557319223985893e-06)
+    BMX_STEP2(2.48015873015873e-05)
+    BMX_STEP2(0.0001984126984126984)
+    BMX_STEP2(0.001388888888888889)
+    BMX_STEP2(0.008333333333333333)
+    BMX_STEP2(0.041666666666666664)
+    BMX_STEP2(0.16666666666666666)
+#undef BMX_STEP2
+    p0 = fma(p0, r0, 0.5); p1 = fma(p1, r1, 0.5);
+    p0 = fma(p0, r0, 1.0); p1 = fma(p1, r1, 1.0);
+    p0 = fma(p0, r0, 1.0); p1 = fma(p1, r1, 1.0);
+    o0 = ldexp(p0, (int)n0);
+    o1 = ldexp(p1, (int)n1);
 }
 
 // Pull the binary exponent out of a non-negative product; a zero product is sticky (-> -inf).
@@ -508,8 +539,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
     const int mom_len = (P.mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER;   // slot 0 in MOM_COPIES copies, slots 1.., 3 spare
     double *mom = lds_tail + (blockDim.x / WAVE) * WAVE * 2 + wave * mom_len;
     // ... and the sites between the group's test sites (position, row * 64): read by the generic passes of all nA iterations
-    double *mid_g = lds_tail + (blockDim.x / WAVE) * (WAVE * 2 + mom_len) + wave * (MID_CAP + MID_CAP / 2);
-    int *mid_ro = reinterpret_cast<int *>(mid_g + MID_CAP);
+    double *mid_base = lds_tail + (blockDim.x / WAVE) * (WAVE * 2 + mom_len);
     if (MODE_ == 3) {
         for (int idx = lane; idx < mom_len; idx += WAVE) mom[idx] = 0.0;
         __builtin_amdgcn_wave_barrier();
@@ -522,7 +552,13 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
     for (int64_t grp = chunk * gpb + wave; grp < g_end; grp += blockDim.x / WAVE) {
         const int64_t tb = grp * J;
         const int nvalid = (int)min((int64_t)J, P.M - tb);
-        const int jj = min(jl, nvalid - 1);
+        // the lane-derived addresses of the group prologue are recomputed per group: left loop-invariant, the compiler
+        // keeps them in registers across the whole kernel and, at 256 VGPRs, in scratch
+        int jl_g = jl, lane_g = lane, wave_g = wave;
+        asm volatile("" : "+v"(jl_g), "+v"(lane_g), "+s"(wave_g));
+        double *mid_g = mid_base + wave_g * (MID_CAP + MID_CAP / 2);
+        int *mid_ro = reinterpret_cast<int *>(mid_g + MID_CAP);
+        const int jj = min(jl_g, nvalid - 1);
         const double tj = P.test_gen[tb + jj];
         int lo_j = (int)max(P.win_lo[tb + jj], (int64_t)0);
         int hi_j = (int)min(P.win_hi[tb + jj], (int64_t)N - 1);
@@ -539,9 +575,9 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
         if (hi_min < lo_max) { L_int = c0; R_int = c0; hi_min = -1; lo_max = N; }   // no bulk zone
         // the sites between the test sites are visited once per A: keep them in LDS (global latency once per group)
         const bool staged = R_int - L_int <= MID_CAP;
-        if (staged && lane < R_int - L_int) {
-            mid_g[lane] = P.genpos[L_int + lane];
-            mid_ro[lane] = (int)P.row[L_int + lane] * WAVE;
+        if (staged && lane_g < R_int - L_int) {
+            mid_g[lane_g] = P.genpos[L_int + lane_g];
+            mid_ro[lane_g] = (int)P.row[L_int + lane_g] * WAVE;
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -604,8 +640,14 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                 const bool inr = dir > 0 ? (i < lim) : (i > lim);
                 // both loads up front: the row is needed only when some site is in a window, but waiting for
                 // the ballot would put two global round trips in series
-                const double g = !inr ? 0.0 : from_lds ? mid_g[i - L_int] : P.genpos[i];
-                const int rowoff = !inr ? 0 : from_lds ? mid_ro[i - L_int] : (int)P.row[i] * WAVE;
+                // (two branches, not a select between an LDS and a global address: that would be a flat load)
+                double g = 0.0;
+                int rowoff = 0;
+                if (from_lds) {
+                    if (inr) { g = mid_g[i - L_int]; rowoff = mid_ro[i - L_int]; }
+                } else {
+                    if (inr) { g = P.genpos[i]; rowoff = (int)P.row[i] * WAVE; }
+                }
                 const bool inwin = inr && i >= lo_j && i <= hi_j;
                 const double z = A * fabs(g - tj);
                 const bool in = inwin && (z <= P.zcut) && (g != tj);
@@ -781,7 +823,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                         t = fma(F[j], t, e2);
                                         t = fma(F[j], t, e1);
                                         acc[j] *= fma(F[j], t, 1.0);
-                                        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 8 chains in flight
+                                        if ((j & (BMX_QSB - 1)) == BMX_QSB - 1) __builtin_amdgcn_sched_barrier(0);   // at most BMX_QSB chains in flight
                                     }
                                 }
                             }
@@ -963,23 +1005,35 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     for (int k = 0; k < FAR_ORDER; ++k) p[k] *= FAR_W[k];
                     int l = 0;
 #pragma unroll
-                    for (int w = 0; w < J; ++w) {
-                        const int j = dir > 0 ? w : J - 1 - w;
-                        if (rag) {
-                            const int nj = __builtin_amdgcn_readlane(nrag_v, j);
-                            for (; l < nj; ++l) {                         // the ragged sites that window j adds
-                                const ScratchEnt en = scr[l];
-                                const double v = en.e * loadR(en.ro), v2 = v * v;
-                                p[0] += v;
-                                p[1] = fma(v2, 0.5, p[1]);
-                                p[2] = fma(v2 * v, 0.3333333333333333, p[2]);
-                            }
-                        }
-                        const double f = F[j];
-                        double t = p[FAR_ORDER - 1];
+                    for (int w = 0; w < J; w += 2) {
+                        // test sites in pairs: the two exps of a pair are interleaved chains (exp_neg2), and the pair's
+                        // products are final before the next pair starts (no tails of 16 exps kept in registers)
+                        double arg[2];
 #pragma unroll
-                        for (int k = FAR_ORDER - 2; k >= 0; --k) t = fma(-f, t, p[k]);
-                        acc[j] *= exp_neg(-f * t);
+                        for (int u = 0; u < 2; ++u) {
+                            const int j = dir > 0 ? w + u : J - 1 - (w + u);
+                            if (rag) {
+                                const int nj = __builtin_amdgcn_readlane(nrag_v, j);
+                                for (; l < nj; ++l) {                         // the ragged sites that window j adds
+                                    const ScratchEnt en = scr[l];
+                                    const double v = en.e * loadR(en.ro), v2 = v * v;
+                                    p[0] += v;
+                                    p[1] = fma(v2, 0.5, p[1]);
+                                    p[2] = fma(v2 * v, 0.3333333333333333, p[2]);
+                                }
+                            }
+                            const double f = F[j];
+                            double t = p[FAR_ORDER - 1];
+#pragma unroll
+                            for (int k = FAR_ORDER - 2; k >= 0; --k) t = fma(-f, t, p[k]);
+                            arg[u] = -f * t;
+                        }
+                        const int j0 = dir > 0 ? w : J - 1 - w, j1 = dir > 0 ? w + 1 : J - 2 - w;
+                        double e0, e1;
+                        exp_neg2(arg[0], arg[1], e0, e1);
+                        acc[j0] *= e0;
+                        acc[j1] *= e1;
+                        asm volatile("" : "+v"(acc[j0]), "+v"(acc[j1]));
                     }
                     PROF_MARK(6);
                     if (rag) {
@@ -1780,9 +1834,9 @@ int plan_scan(bmx_ctx *c, ScanPlan &pl) {
     if (lds_bytes) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     P.sites_per_block = spb;
     pl.fn = fn; pl.J = J; pl.threads = threads; pl.lds_bytes = lds_bytes; pl.spb = spb;
-    // test sites per launch: keeps the per-slice winners (16 B x slices per test site) within ~256 MB and the grid
+    // test sites per launch: keeps the per-slice winners (16 B x slices per test site) within ~512 MB and the grid
     // within 2^31 workgroups; a multiple of the workgroup's share, so ranges cut the test sites where workgroups do
-    int64_t range = std::max<int64_t>((int64_t)(256u << 20) / (16 * (int64_t)c->nslices), spb);
+    int64_t range = std::max<int64_t>((int64_t)(512u << 20) / (16 * (int64_t)c->nslices), spb);
     range = std::min<int64_t>(range, (int64_t)0x7fffff00LL / c->nslices * spb);
     range = std::max<int64_t>(range / spb, 1) * spb;
     pl.range = range;

@@ -1,0 +1,74 @@
+"""Turns the counter CSVs of scripts/pmc_collect.sh into the per-evaluation / per-window figures bench.py's roofline uses.
+    python scripts/pmc_calibrate.py <tag> <dir>     -> prints a summary and the JSON entry for profiles/r02_pmc_calibration.json
+All counters are summed over the dispatches of the scan kernel in one bench step; evaluations and windows of that step come
+from the bench line of the same process (evals_per_step: sum over test sites of |x| |alpha| sum_A W_A)."""
+import collections, csv, glob, json, os, sys
+
+tag, root = sys.argv[1], sys.argv[2]
+tot = collections.defaultdict(float)
+ndisp = {}
+dur = {}
+for p in sorted(glob.glob(os.path.join(root, '*'))):
+    if not os.path.isdir(p):
+        continue
+    name = os.path.basename(p)
+    for f in glob.glob(os.path.join(p, '**', '*counter_collection.csv'), recursive=True):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            if 'clr_scan' not in r['Kernel_Name']:
+                continue
+            tot[r['Counter_Name']] += float(r['Counter_Value'])
+            seen.add(r['Dispatch_Id'])
+        ndisp[name] = len(seen)
+    for f in glob.glob(os.path.join(p, '**', '*kernel_trace.csv'), recursive=True):
+        d = 0.0
+        for r in csv.DictReader(open(f)):
+            if 'clr_scan' in r['Kernel_Name']:
+                d += (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-6
+        dur[name] = d
+bench = None
+for p in sorted(glob.glob(os.path.join(root, '*.json'))):
+    try:
+        lines = [l for l in open(p).read().splitlines() if l.startswith('{')]
+        bench = json.loads(lines[-1])
+        break
+    except Exception:
+        pass
+if bench is None:
+    raise SystemExit('no bench line found under ' + root)
+evals = bench['roofline']['evals_per_step']
+windows = bench['config']['windows_per_step']
+print('%s: %d scan-kernel dispatches per pass %s, %.4g evaluations, %d windows; profiled kernel time per pass (ms): %s'
+      % (tag, max(ndisp.values() or [0]), dict(ndisp), evals, windows, {k: round(v, 1) for k, v in dur.items()}))
+for k in sorted(tot):
+    print('   %-28s %.6g' % (k, tot[k]))
+g = lambda k: tot.get(k, 0.0)
+valu = g('SQ_INSTS_VALU')
+fma, mul, add, trans = g('SQ_INSTS_VALU_FMA_F64'), g('SQ_INSTS_VALU_MUL_F64'), g('SQ_INSTS_VALU_ADD_F64'), g('SQ_INSTS_VALU_TRANS_F64')
+flops = (2 * fma + mul + add + trans) * 64.0
+cyc = g('GRBM_GUI_ACTIVE') / 8.0
+simds = 1024.0
+entry = {
+    'valu_per_64_evals': valu / (evals / 64.0),
+    'fp64_fma_per_64_evals': fma / (evals / 64.0), 'fp64_mul_per_64_evals': mul / (evals / 64.0),
+    'fp64_add_per_64_evals': add / (evals / 64.0), 'fp64_trans_per_64_evals': trans / (evals / 64.0),
+    'fp64_flops_per_eval': flops / evals,
+    'fp64_share_of_valu': (fma + mul + add + trans) / valu if valu else None,
+    'int32_per_64_evals': g('SQ_INSTS_VALU_INT32') / (evals / 64.0), 'int64_per_64_evals': g('SQ_INSTS_VALU_INT64') / (evals / 64.0),
+    'cvt_per_64_evals': g('SQ_INSTS_VALU_CVT') / (evals / 64.0),
+    'salu_per_64_evals': g('SQ_INSTS_SALU') / (evals / 64.0), 'lds_per_64_evals': g('SQ_INSTS_LDS') / (evals / 64.0),
+    'cycles_per_valu_per_simd': cyc * simds / valu if valu else None,
+    'effective_clock_ghz': cyc / (dur.get('B', 0) * 1e-3) / 1e9 if dur.get('B') else None,
+    'wait_any_share': g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES') if g('SQ_WAVE_CYCLES') else None,
+    'wait_inst_any_share': g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES') if g('SQ_WAVE_CYCLES') else None,
+    'lds_bank_conflict_share': g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE') if g('SQ_LDS_IDX_ACTIVE') else None,
+    'l2_hit_rate': g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')) if g('TCC_HIT_sum') + g('TCC_MISS_sum') else None,
+    # FETCH_SIZE / WRITE_SIZE are reported in KB; the guide's gfx950 correction doubles FETCH_SIZE (it counts 128-B requests as 64 B)
+    'hbm_read_bytes_per_window': g('FETCH_SIZE') * 1024.0 * 2.0 / windows,
+    'hbm_write_bytes_per_window': g('WRITE_SIZE') * 1024.0 / windows,
+    'windows': windows, 'evals': evals, 'dispatches': max(ndisp.values() or [0]),
+    'kernel_ms_profiled': dur,
+    'source': 'rocprofv3 --pmc passes A-E of `python3 bench.py %s --steps 1 --warmup 0 --no-cpu-baseline` (scripts/pmc_collect.sh %s), '
+              'profiles/r02_pmc_%s_summary.txt' % (' '.join(sys.argv[3:]) or '--config ' + tag.strip('c'), tag, tag),
+}
+print(json.dumps({('config' + tag.strip('c')): entry}, indent=1))
