@@ -121,7 +121,7 @@ def main(argv=None):
         sys.exit(1)
     runner = world.sharded_runner(block=block) if world.distributed else None
     Scan(data, Neutral, Sel_Probs, grid, opt.outfile if world.rank == 0 else None, fixSize=opt.size, r=opt.w,
-         s=opt.step, phys=opt.phys, noCenter=opt.noCenter, runner=runner, verbose=verbose)
+         s=opt.step, phys=opt.phys, noCenter=opt.noCenter, runner=runner, verbose=verbose, keep_results=False)
     world.finish()
     say(f'\n{datetime.now()}. Pipeline finished.')
 

@@ -48,6 +48,9 @@ class ModelArrays:
         self.abeta = _lib.f64(abetas)
         self.min_count = int(min_count)
         self._off_of = {int(n): int(o) for n, o in zip(self.sizes, self.row_off[:-1])}
+        # two models with equal keys build bit-identical device tables
+        self.key = (stat, self.min_count, self.sizes.tobytes(), self.g.tobytes(), self.prop.tobytes(), self.x.tobytes(),
+                    self.abeta.tobytes())
         self.c = BmxModel(STAT_IDS[stat], self.min_count, len(self.sizes), _lib.as_ip(self.sizes),
                           _lib.as_ip(self.row_off), _lib.as_dp(self.g), _lib.as_dp(self.prop),
                           len(self.x), _lib.as_dp(self.x), len(self.abeta), _lib.as_dp(self.abeta))
@@ -185,8 +188,10 @@ class NormalizedBetaBinom:
             for j, a in enumerate(self.grid_abeta):
                 self._key[(x, a)] = (i, j)
 
-    def bind(self, NeutralSFS):
-        """Create (once per NeutralSFS) the resident context: K1 table + site arrays in HBM."""
+    def bind(self, NeutralSFS, reuse=None):
+        """Create (once per NeutralSFS) the resident context: K1 table + site arrays in HBM.
+        reuse: a Context that already holds this model and A grid (e.g. the previous chromosome's, whole-genome runs):
+        its table and buffers are kept and only the site arrays are replaced."""
         if self._bound_to is NeutralSFS and self.ctx is not None:
             return self
         d = self._data
@@ -197,10 +202,17 @@ class NormalizedBetaBinom:
             spect, props = NeutralSFS.spect, NeutralSFS.sampProps
         self.model = ModelArrays(self.stat, d.minCount, d.sampSizes, spect, props, self.grid_x, self.grid_abeta)
         self.rows = self.model.rows_of(d.count, d.total)
-        if self.ctx is not None:
+        if self.ctx is not None and self.ctx is not reuse:
             self.ctx.close()
-        self.ctx = Context(self._device)
-        self.ctx.set_model(self.model, self.grid_A)
+        akey = tuple(float(a) for a in self.grid_A)
+        if reuse is not None and getattr(reuse, 'model', None) is not None and reuse.model.key == self.model.key and \
+                getattr(reuse, 'A_key', None) == akey and reuse.device == self._device:
+            self.ctx = reuse
+            self.ctx.model = self.model
+        else:
+            self.ctx = Context(self._device)
+            self.ctx.set_model(self.model, self.grid_A)
+            self.ctx.A_key = akey
         self.ctx.set_sites(d.genPos, self.rows)
         self._bound_to = NeutralSFS
         self._psel = None
@@ -216,13 +228,13 @@ class NormalizedBetaBinom:
         return self._psel[i, j][self.rows]
 
 
-def scan_stream(sel, test_gen, win_lo, win_hi, outfile, phys, gen_label):
+def scan_stream(sel, test_gen, win_lo, win_hi, outfile, phys, gen_label, fetch=True):
     """scan_batch + the output rows appended to `outfile` while the scan runs (the reference writes as it scans,
-    v1:599-608).  Returns what scan_batch returns."""
+    v1:599-608).  Returns what scan_batch returns (None with fetch=False: the file is all the caller wants)."""
     sel.ctx.set_tests(test_gen, win_lo, win_hi)
     sel.ctx.scan_write(outfile, phys, gen_label, [f'{v}' for v in sel.grid_x], [f'{v}' for v in sel.grid_abeta],
                        [f'{v}' for v in sel.grid_A])
-    return sel.ctx.fetch()
+    return sel.ctx.fetch() if fetch else None
 
 
 def scan_batch(sel, test_gen, win_lo, win_hi):

@@ -227,17 +227,18 @@ class NeutralSFS:
         """Checks that every (k, n) in the input is covered by the helper file.  The per-site
         arrays of the reference are replaced by the (k,n)-indexed table handed to the kernels
         (SelectionTable); probs/logProbs/propSizes are still filled for API compatibility."""
-        combos = set(zip(data.count.tolist(), data.total.tolist()))
-        if not combos.issubset(set(self.spect.keys())):
+        # the distinct (k, n) of the input, through one integer key per site (a Python set of 40M tuples is what a
+        # whole-genome run would otherwise spend its host time on)
+        base = int(data.total.max()) + 1 if data.numSites else 1
+        key = np.asarray(data.count).astype(np.int64) * base + np.asarray(data.total).astype(np.int64)
+        uk, inv = np.unique(key, return_inverse=True)
+        combos = [(int(u) // base, int(u) % base) for u in uk]
+        if any(c not in self.spect for c in combos):
             print('Input data includes sample counts and sizes not included in the helper file. Please double-check your inputs.')
             sys.exit()
         if len(self.probs) == 0:
-            lut = {c: self.spect[c] for c in combos}
-            key = data.count.astype(np.int64) * (int(data.total.max()) + 1) + data.total.astype(np.int64)
-            uk, inv = np.unique(key, return_inverse=True)
-            vals = np.array([lut[(int(u) // (int(data.total.max()) + 1), int(u) % (int(data.total.max()) + 1))]
-                             for u in uk])
-            self.probs = vals[inv]
+            vals = np.array([self.spect[c] for c in combos], dtype=np.float64)
+            self.probs = vals[inv] if len(vals) else np.zeros(0)
         assert len(self.probs) == data.numSites
         if len(self.logProbs) == 0:
             self.logProbs = np.log(self.probs)

@@ -237,8 +237,10 @@ class Scan:
     """v1:510-640: same constructor, same dispatch, same messages."""
 
     def __init__(self, InputData, NeutralSFS, NormalizedBetaBinom, Grids, outfile, fixSize=False, r=0, s=1,
-                 phys=False, noCenter=False, runner=None, verbose=True):
-        # verbose=False: the ranks of a multi-GPU run that do not write the output stay silent
+                 phys=False, noCenter=False, runner=None, verbose=True, keep_results=True, reuse_ctx=None):
+        # verbose=False: the ranks of a multi-GPU run that do not write the output stay silent; keep_results=False: the
+        # output file is all the caller wants (self.results stays None when the rows were streamed to it);
+        # reuse_ctx: a scan context of the same model to keep using (whole-genome runs, engine.NormalizedBetaBinom.bind)
         say = print if verbose else (lambda *a, **k: None)
         if fixSize:
             say('You\'ve chosen to fix the size (in nt) of sliding window for scanning.')
@@ -262,7 +264,7 @@ class Scan:
             say(('Computing LR on every %s site/s, using informative sites with exp(-A*dist) >= 1e-8.' % (s)))
             ts = sites_alpha(InputData, s)
         say(("writing output to %s" % (outfile)))
-        NormalizedBetaBinom.bind(NeutralSFS)
+        NormalizedBetaBinom.bind(NeutralSFS, reuse=reuse_ctx) if reuse_ctx is not None else NormalizedBetaBinom.bind(NeutralSFS)
         run = runner or engine.scan_batch
         streamed = False
         if len(ts):
@@ -271,7 +273,7 @@ class Scan:
                 with open(outfile, 'w') as scores:
                     scores.write(HEADER)
                 results = engine.scan_stream(NormalizedBetaBinom, ts.arrays[1], ts.arrays[2], ts.arrays[3], outfile,
-                                             ts.arrays[0], ts.arrays[1])
+                                             ts.arrays[0], ts.arrays[1], fetch=keep_results)
                 streamed = True
             elif ts.arrays is not None:
                 results = run(NormalizedBetaBinom, ts.arrays[1], ts.arrays[2], ts.arrays[3])
