@@ -66,6 +66,10 @@ def build_parser():
 
 
 def main(argv=None):
+    import time
+    t_start = time.time()
+    stamp = (lambda what: print('[bmx cli] %-28s %.3f s' % (what, time.time() - t_start), file=sys.stderr)) \
+        if os.environ.get('BMX_TRACE') else (lambda what: None)
     argv = sys.argv[1:] if argv is None else argv
     parser = build_parser()
     if len(argv) == 0:
@@ -101,6 +105,20 @@ def main(argv=None):
         if verbose:
             print(*a)
 
+    stamp('imports, process group')
+    # The HIP runtime and the context take ~0.2 s to come up: start them now, on a helper thread, while this thread reads
+    # the input and the helper file (the native calls release the GIL); engine.NormalizedBetaBinom picks the context up.
+    import threading
+    warm = {}
+
+    def _warm():
+        try:
+            warm['ctx'] = engine.Context(device)
+        except Exception as e:          # reported by the main thread where the reference-style flow creates the context
+            warm['err'] = e
+
+    warm_thread = threading.Thread(target=_warm)
+    warm_thread.start()
     say(f"\n{datetime.now()}. Reading input from {opt.infile}")
     data = InputData(opt.infile, opt.nofreq, opt.MAF, opt.nosub, opt.minCount, phys=opt.phys, Rrate=opt.Rrate)
     Neutral = NeutralSFS(opt.spectfile, opt.nofreq, opt.MAF, opt.nosub)
@@ -111,7 +129,12 @@ def main(argv=None):
     say('\nOptimizing over x= ' + ', '.join(['%g' % (x) for x in grid.x]))
     say('\n \t alpha= ' + ', '.join([str(a) for a in grid.abeta]))
     say('\n \t A= ' + ', '.join([str(A) for A in grid.A]))
-    Sel_Probs = engine.NormalizedBetaBinom(data, grid, opt.nofreq, opt.MAF, opt.nosub, device=device)
+    stamp('input, neutral model, grids')
+    warm_thread.join()
+    if 'err' in warm:
+        raise warm['err']
+    stamp('HIP context ready')
+    Sel_Probs = engine.NormalizedBetaBinom(data, grid, opt.nofreq, opt.MAF, opt.nosub, device=device, ctx=warm['ctx'])
     say(("\n%s. Start computing likelihood ratios..." % (datetime.now())))
     # BMX_SHARD_BLOCK: test sites per shard block (default distributed.BLOCK = 4096; a multiple of 16 keeps every window's
     # arithmetic independent of the number of ranks) -- lets small inputs exercise real sharding in the tests
@@ -122,6 +145,7 @@ def main(argv=None):
     runner = world.sharded_runner(block=block) if world.distributed else None
     Scan(data, Neutral, Sel_Probs, grid, opt.outfile if world.rank == 0 else None, fixSize=opt.size, r=opt.w,
          s=opt.step, phys=opt.phys, noCenter=opt.noCenter, runner=runner, verbose=verbose, keep_results=False)
+    stamp('table, scan, output')
     world.finish()
     say(f'\n{datetime.now()}. Pipeline finished.')
 

@@ -175,7 +175,9 @@ class NormalizedBetaBinom:
     reference only supplies at calcBaller time, so the device state is created on first use
     (`bind`), when the NeutralSFS is known."""
 
-    def __init__(self, InputData, Grids, nofreq, MAF, nosub, device=0):
+    def __init__(self, InputData, Grids, nofreq, MAF, nosub, device=0, ctx=None):
+        # ctx: an empty Context created ahead of time (the CLI brings the HIP runtime up while it parses the input)
+        self._fresh_ctx = ctx
         self.stat = stat_name(nofreq, MAF, nosub)
         self.grid_x, self.grid_abeta, self.grid_A = Grids.scan_order()
         self._data = InputData
@@ -210,7 +212,10 @@ class NormalizedBetaBinom:
             self.ctx = reuse
             self.ctx.model = self.model
         else:
-            self.ctx = Context(self._device)
+            if self._fresh_ctx is not None and self._fresh_ctx.device == self._device:
+                self.ctx, self._fresh_ctx = self._fresh_ctx, None
+            else:
+                self.ctx = Context(self._device)
             self.ctx.set_model(self.model, self.grid_A)
             self.ctx.A_key = akey
         self.ctx.set_sites(d.genPos, self.rows)
