@@ -1776,7 +1776,7 @@ int plan_scan(bmx_ctx *c, ScanPlan &pl) {
     };
     while (mom_slots >= 8 && lds_need(mom_slots) > (size_t)LDS_LIMIT_BYTES) mom_slots /= 2;
     if (mom_slots < 8) mom_slots = 0;
-    const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES;
+    const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES && !diag_env("BMX_NO_LDS");   // BMX_NO_LDS: R from L2 (A/B runs)
     if (!fits || c->variant == 1) mom_slots = MOM_SLOTS;
     P.mom_slots = mom_slots;
     // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3

@@ -328,7 +328,7 @@ def _run():
         windows = float(windows_per_step) * args.steps
         evals_s = evals_per_step / k_step_s
         cal = load_calibration(args.config)
-        kname = 'clr_scan_grouped_kernel<16,true,3>' if args.config != 5 or True else ''
+        kname = 'clr_scan_grouped_kernel<16,true,3>'
         workload = {
             4: 'BASELINE config 4: synthetic whole genome, %d SNPs over %d chromosomes (GRCh37 proportions), n=%d, default '
                '31x10x51 (A,x,alpha) grid, B2 scan, every SNP a test site; site arrays of all chromosomes resident on every GPU, '

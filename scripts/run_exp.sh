@@ -1,4 +1,9 @@
 mkdir -p gpurun_out
-python scripts/e2e_timing.py > gpurun_out/e2e_r02.txt 2>&1; grep "CLI end" gpurun_out/e2e_r02.txt
-for i in 1 2 3; do s=$(date +%s.%N); BMX_TRACE=1 python BalLeRMixPlus_amd.py -i /tmp/bmx_e2e_in.txt --spect /tmp/bmx_e2e_spect.txt -o /tmp/o.txt 2>&1 | grep -E "bmx cli" | tr '\n' ';'; e=$(date +%s.%N); echo " wall $(echo "$e - $s" | bc)"; done
-s=$(date +%s.%N); python -c "import numpy" ; e=$(date +%s.%N); echo "python+numpy $(echo "$e - $s" | bc)"
+O=gpurun_out/exp16.txt
+: > $O
+export BMX_LIB_NAME=libbmx_diag.so
+python scripts/kexp.py --config 5 --windows 131072 --tag c5_lds >> $O 2>&1
+BMX_NO_LDS=1 python scripts/kexp.py --config 5 --windows 131072 --tag c5_l2 >> $O 2>&1
+BMX_NO_LDS=1 python scripts/kexp.py --config 3 --windows 131072 --tag c3_l2 >> $O 2>&1
+BMX_NO_LDS=1 BMX_MOM_SLOTS=64 python scripts/kexp.py --config 5 --windows 131072 --tag c5_l2_64slots >> $O 2>&1
+cat $O | cut -c1-130

@@ -245,6 +245,30 @@ def test_native_row_writer_writes_the_same_bytes(tmp_path):
     assert rows[0] == 'physPos\tgenPos\tCLR\tx_hat\ts_hat\tA_hat\tnSites' and len(rows) == N + 1
 
 
+def test_native_row_writer_on_several_threads(tmp_path):
+    """Beyond 8192 rows the formatter splits a chunk over host threads (and bmx_write_rows works in chunks of 2^18 rows):
+    same bytes as Python's own f-string of the same values, all-zero rows included."""
+    from ballermixplus_amd import _lib
+    N = 300000
+    rg = np.random.default_rng(11)
+    phys = np.cumsum(rg.integers(1, 200, N)).astype(np.int64)
+    gen = phys / 1e6
+    clr = rg.random(N) * 10.0 ** rg.integers(-9, 4, N)
+    ix, ia = rg.integers(0, 10, N).astype(np.int32), rg.integers(0, 51, N).astype(np.int32)
+    iA, ns = rg.integers(-1, 31, N).astype(np.int32), rg.integers(1, 6000, N).astype(np.int32)
+    g = Grids(None, None, False, False, None, None)
+    xs, ab, As = g.scan_order()
+    sx, sa, sA = [f'{v}' for v in xs], [f'{v}' for v in ab], [f'{v}' for v in As]
+    out = tmp_path / 'rows.txt'
+    _lib.write_rows(str(out), phys, gen, clr, ix, ia, iA, ns, sx, sa, sA)
+    want = ''.join(f'{p}\t{float(q)}\t{float(c)}\t{sx[a]}\t{sa[b]}\t{sA[d]}\t{n}\n' if d >= 0 else f'{p}\t{float(q)}\t0.0\t0.0\t0.0\t0.0\t0.0\n'
+                   for p, q, c, a, b, d, n in zip(phys.tolist(), gen.tolist(), clr.tolist(), ix.tolist(), ia.tolist(), iA.tolist(), ns.tolist()))
+    assert out.read_text() == want
+    iA[12345] = 31                                       # a grid index outside the tables is an error, not a crash
+    with pytest.raises(_lib.BmxError):
+        _lib.write_rows(str(out), phys, gen, clr, ix, ia, iA, ns, sx, sa, sA)
+
+
 def test_vectorised_window_generation_equals_the_reference_loops(monkeypatch):
     """sites_site_based / sites_fix_center fast paths vs the reference's per-site loops."""
     from ballermixplus_amd import scan as scanmod
