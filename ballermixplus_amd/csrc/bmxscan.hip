@@ -1660,7 +1660,8 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
         for (int a = 0; a < c->nA; a++) {
             const double nfar = range > 0 ? 0.8 * (double)(N - 1) / range * c->zcut / c->h_A[(size_t)a] : (double)N;
             int k = 0;
-            while (k < nslots && k < kcap && (double)cnt[(size_t)c->row_of_slot[k]] / (double)N * nfar * 23.0 > 30.0) k++;
+            const double gain = diag_env("BMX_KMOM_GAIN") ? atof(diag_env("BMX_KMOM_GAIN")) : 23.0;      // threshold experiments
+            while (k < nslots && k < kcap && (double)cnt[(size_t)c->row_of_slot[k]] / (double)N * nfar * gain > 30.0) k++;
             km[(size_t)a] = (uint8_t)k;
         }
         // the kernel reads max |R| and the slot of a row with one load: the slot sits in the low mantissa

@@ -1,9 +1,3 @@
-mkdir -p gpurun_out
-O=gpurun_out/exp16.txt
-: > $O
+python -m pytest tests/test_gpu_round2.py -x -q -k "more_test_sites" 2>&1 | tail -4
 export BMX_LIB_NAME=libbmx_diag.so
-python scripts/kexp.py --config 5 --windows 131072 --tag c5_lds >> $O 2>&1
-BMX_NO_LDS=1 python scripts/kexp.py --config 5 --windows 131072 --tag c5_l2 >> $O 2>&1
-BMX_NO_LDS=1 python scripts/kexp.py --config 3 --windows 131072 --tag c3_l2 >> $O 2>&1
-BMX_NO_LDS=1 BMX_MOM_SLOTS=64 python scripts/kexp.py --config 5 --windows 131072 --tag c5_l2_64slots >> $O 2>&1
-cat $O | cut -c1-130
+for g in 8 15 23 35 50 80 150; do BMX_KMOM_GAIN=$g python scripts/kexp.py --tag gain$g 2>&1 | cut -c1-110; done

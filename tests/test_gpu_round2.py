@@ -422,3 +422,31 @@ def test_config5_two_contigs_at_full_size():
         assert np.max(np.abs(c2 - clr[blk]) / np.maximum(clr[blk], 1e-9)) < 1e-9
     ctx.close()
     assert found == 2, 'reference fixtures missing'
+
+
+def test_more_test_sites_than_one_launch_covers():
+    """A scan is launched in ranges of at most 4 194 304 test sites (512 MB of per-slice winners at 8 slices): 4.4M windows on
+    one chromosome take two launches, and the windows on either side of the cut equal a separate scan of just those test sites
+    bitwise (ranges end where workgroups do); the streaming writer's chunks obey the same rule."""
+    from ballermixplus_amd import engine as eng, synth
+    from ballermixplus_amd.hostmodel import Grids
+    N = 4400000
+    phys, gen, k, nn = synth.synth_chromosome(N, 100, 13)
+    spect = {(a, b): f for a, b, f in synth.spect_from_counts(k, nn)}
+    grid = Grids(None, None, False, False, None, None)
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays('B2', int(k.min()), [100], spect, {100: 1.0}, xs, ab)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, model.rows_of(k, nn))
+    ctx.set_tests(gen, np.zeros(N, np.int64), np.full(N, N - 1, np.int64))
+    ctx.scan()
+    full = ctx.fetch()
+    assert np.all(np.isfinite(full[0])) and np.all(full[0] >= 0)
+    for lo in (4194304 - 2048, N - 4096 - (N - 4096) % 16, 0):
+        idx = np.arange(lo, lo + 4096)
+        ctx.set_tests(gen[idx], np.zeros(4096, np.int64), np.full(4096, N - 1, np.int64))
+        ctx.scan()
+        part = ctx.fetch()
+        assert all(np.array_equal(a[idx], b) for a, b in zip(full, part)), lo
+    ctx.close()
