@@ -84,6 +84,8 @@ bool trace_on() {
 constexpr int WAVE = 64;
 constexpr int SCAN_THREADS = 256;             // 4 waves per workgroup (default)
 constexpr int SCAN_THREADS_MAX = 512;         // 8 waves when one R slice fills most of a CU's LDS
+constexpr int SITE_THREADS = 1024;            // per-site kernel: 16 waves per workgroup, two workgroups per CU = 8 waves per SIMD
+                                              // (62 VGPRs; the kernel is latency-bound per pass and lives on occupancy)
 constexpr int LDS_LIMIT_BYTES = 160 * 1024;   // gfx950: 160 KiB per CU
 constexpr int MOM_SLOTS = 254;                // grouped kernel: rows whose far-field sites can be summed as moments
 constexpr int MOM_SLOTS_LDS = 64;             // ... of which this many are used while the R slice occupies the LDS
@@ -343,106 +345,128 @@ __device__ __forceinline__ void renorm(double &acc, int &E) {
     acc = __hiloint2double((int)hi, __double2loint(acc));
 }
 
+// One (E or alpha, row * 64) entry of a wave's scratch list in LDS: written lanes-over-sites, read back with a uniform
+// address (LDS broadcast) by all 64 grid-pair lanes.
+struct alignas(16) ScratchEnt {
+    double e;
+    int ro;   // row * 64
+    int pad;
+};
+
+// K2, one test site per wave: sparse test sets (the reference's -s with a large step), unsorted test positions, tables whose
+// dynamic range is too wide for block-wise exponent extraction; also the independent cross-check of the grouped kernel in the
+// tests.  Per A and side the wave walks the window 64 sites at a time: alpha = exp(-A d) lanes-over-sites, (alpha, row) through
+// the wave's LDS scratch, then every lane (grid pair) multiplies 1 + alpha R four sites per step: 2.75 vector instructions
+// per site (round 1: ~6 with v_readlane broadcasts and OCML's exp).  Best grid point tracked per lane as (exponent, mantissa),
+// like the grouped kernel; finalize_kernel takes the one log and counts nSites.
 template <bool USE_LDS>
-__global__ __launch_bounds__(SCAN_THREADS) void clr_scan_kernel(ScanParams P) {
-    extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS
+__global__ __launch_bounds__(SITE_THREADS) void clr_scan_kernel(ScanParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then 64 entries per wave
     const int lane = threadIdx.x & (WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform: group-level scalars live in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x / WAVE;
     const int slice = blockIdx.x % P.nslices;   // blocks b, b+8 share an XCD: one R slice per L2
     const int64_t chunk = blockIdx.x / P.nslices;
     const int p = slice * WAVE + lane;
+    const int N = (int)P.N;
 
     if (USE_LDS) {
         const int total = P.rows * WAVE;
-        for (int idx = threadIdx.x; idx < total; idx += SCAN_THREADS)
+        for (int idx = threadIdx.x; idx < total; idx += blockDim.x)
             lds_R[idx] = P.Rt[(size_t)(idx >> 6) * P.NP + slice * WAVE + (idx & 63)];
         __syncthreads();
     }
     const double *Rg = P.Rt + slice * WAVE + lane;
+    auto loadR = [&](int rowoff) -> double {                       // rowoff = row * 64
+        return USE_LDS ? lds_R[rowoff + lane] : Rg[(size_t)(rowoff >> 6) * P.NP];
+    };
+    ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_R + (USE_LDS ? P.rows * WAVE : 0)) + wave * WAVE;
 
     const int64_t t_begin = chunk * P.sites_per_block;
     const int64_t t_end = min(t_begin + (int64_t)P.sites_per_block, P.M);
-    for (int64_t t = t_begin + wave; t < t_end; t += SCAN_THREADS / WAVE) {
+    for (int64_t t = t_begin + wave; t < t_end; t += nw) {
         const double tg = P.test_gen[t];
-        int64_t lo = max(P.win_lo[t], (int64_t)0);
-        int64_t hi = min(P.win_hi[t], P.N - 1);
-        const int64_t c = P.center[t];
-        double bestT = 0.0;
-        int bestLin = 0x7fffffff, bestNs = 0;
+        const int lo = (int)max(P.win_lo[t], (int64_t)0);
+        const int hi = (int)min(P.win_hi[t], (int64_t)N - 1);
+        const int c = (int)P.center[t];
+        double bestM = 1.0;
+        int bestK = (131072 << 13) | 8191;          // (clamped exponent + 2^17) << 13 | iA; iA = 8191: none yet
 
         for (int iA = 0; iA < P.nA; ++iA) {
             const double Aval = P.A[iA];
             double acc = 1.0;
-            int E = 0, ns = 0, since = 0;
+            int E = 0, since = 0;
             for (int dir = 0; dir < 2; ++dir) {
                 // dir 0: indices c, c+1, ... up to hi;  dir 1: c-1, c-2, ... down to lo
-                int64_t base = dir == 0 ? max(c, lo) : min(c - 1, hi);
+                int base = dir == 0 ? max(c, lo) : min(c - 1, hi);
+                int i = dir == 0 ? base + lane : base - lane;
+                double g_nx = P.genpos[min(max(i, 0), N - 1)];          // the next pass's sites are requested one pass ahead
+                int r_nx = (int)P.row[min(max(i, 0), N - 1)];
                 while (true) {
-                    const int64_t i = dir == 0 ? base + lane : base - lane;
                     const bool valid = (i >= lo) && (i <= hi);
-                    const double g = valid ? P.genpos[i] : tg;
+                    const double g = g_nx;
+                    const int rraw = r_nx;
+                    const int inx = dir == 0 ? i + WAVE : i - WAVE;
+                    g_nx = P.genpos[min(max(inx, 0), N - 1)];
+                    r_nx = (int)P.row[min(max(inx, 0), N - 1)];
                     const double z = Aval * fabs(g - tg);
                     const bool in = valid && (z <= P.zcut) && (g != tg);
                     const bool beyond = valid && (z > P.zcut);
-                    const double alpha = in ? exp(-z) : 0.0;
                     const unsigned long long m_in = __ballot(in);
-                    ns += __popcll(m_in);
                     const int cnt = m_in ? 64 - __clzll((long long)m_in) : 0;
-                    // lanes that are not in the window carry alpha = 0; give them the row of an in-window
-                    // lane so that 0*R is 0 and never 0*NaN (rows absent from the helper file hold NaN)
-                    int rowi = valid ? (int)P.row[i] : 0;
-                    if (cnt) rowi = in ? rowi : __builtin_amdgcn_readlane(rowi, __ffsll((long long)m_in) - 1);
-                    // four sites per iteration: the four R reads are in flight together, two
-                    // independent product chains
-                    for (int l = 0; l < cnt; l += 4) {
-                        double Rv[4], av[4];
+                    if (cnt) {
+                        // lanes outside the window carry alpha = 0; give them the row of an in-window lane so that
+                        // 0*R is 0 and never 0*NaN (rows absent from the helper file hold NaN)
+                        const int rowoff = (in ? rraw : __builtin_amdgcn_readlane(rraw, __ffsll((long long)m_in) - 1)) * WAVE;
+                        scr[lane] = ScratchEnt{in ? exp_neg(z) : 0.0, rowoff, 0};
+                        __builtin_amdgcn_wave_barrier();
+                        // (no prefetch of the next step's entries, and the entry as an 8-byte + a 4-byte read rather than one 16-byte
+                        // read: with 8 waves per SIMD the LDS round trips are covered by the other waves; both variants were
+                        // measured slower, by 17 % and 4 %)
+                        for (int l = 0; l < cnt; l += 4) {
+                            double f[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int ll = min(l + u, WAVE - 1);
-                            av[u] = readlane_f64(alpha, ll);
-                            const int r_s = __builtin_amdgcn_readlane(rowi, ll);
-                            Rv[u] = USE_LDS ? lds_R[r_s * WAVE + lane] : Rg[(size_t)r_s * P.NP];
+                            for (int u = 0; u < 4; ++u) {
+                                const ScratchEnt en = scr[min(l + u, WAVE - 1)];      // uniform address: LDS broadcast
+                                f[u] = fma(en.e, loadR(en.ro), 1.0);
+                            }
+                            acc *= (f[0] * f[1]) * (f[2] * f[3]);
+                            since += 4;
+                            if (since + 4 > P.renorm_every) {
+                                renorm(acc, E);
+                                since = 0;
+                            }
                         }
-                        const double t01 = fma(av[0], Rv[0], 1.0) * fma(av[1], Rv[1], 1.0);
-                        const double t23 = fma(av[2], Rv[2], 1.0) * fma(av[3], Rv[3], 1.0);
-                        acc *= t01 * t23;
-                        since += 4;
-                        if (since + 4 > P.renorm_every) {
-                            renorm(acc, E);
-                            since = 0;
-                        }
+                        __builtin_amdgcn_wave_barrier();
                     }
                     if (__ballot(beyond) != 0ull || __ballot(valid) != ~0ull) break;
-                    base += dir == 0 ? WAVE : -WAVE;
+                    i = inx;
                 }
             }
-            if (ns > 0) {
-                renorm(acc, E);
-                const double T = 2.0 * ((double)E * LN2 + log(acc));
-                if (p < P.npairs && T > bestT) {      // strict '>' (v1:501); iA ascending
-                    bestT = T;
-                    bestLin = iA * P.npairs + p;
-                    bestNs = ns;
-                }
+            renorm(acc, E);
+            const int ec = min(max(E, -131071), 131071) + 131072;
+            const int eb = bestK >> 13;
+            if (((ec > eb) || (ec == eb && acc > bestM)) && p < P.npairs) {       // strict '>' (v1:501); iA ascending
+                bestM = acc;
+                bestK = (ec << 13) | iA;
             }
         }
-        // wave argmax: larger T wins, ties go to the smaller linear index = the reference's
-        // first strict maximum in (A, x, alpha_beta) loop order
+        // wave argmax on (exponent, mantissa), ties to the smaller linear index = the reference's first strict
+        // maximum in (A, x, alpha_beta) loop order; the logarithm is finalize_kernel's
+        const int biA = bestK & 8191;
+        int bE = bestK >> 13;
+        int bL = biA == 8191 ? 0x7fffffff : biA * P.npairs + p;
         for (int off = 32; off > 0; off >>= 1) {
-            const double oT = __shfl_xor(bestT, off);
-            const int oL = __shfl_xor(bestLin, off);
-            const int oN = __shfl_xor(bestNs, off);
-            if (oT > bestT || (oT == bestT && oL < bestLin)) {
-                bestT = oT;
-                bestLin = oL;
-                bestNs = oN;
-            }
+            const int oE = __shfl_xor(bE, off);
+            const double oM = __shfl_xor(bestM, off);
+            const int oL = __shfl_xor(bL, off);
+            if (oE > bE || (oE == bE && (oM > bestM || (oM == bestM && oL < bL)))) { bE = oE; bestM = oM; bL = oL; }
         }
         if (lane == 0) {
             const size_t o = (size_t)slice * P.M + t;          // [slice][M]: coalesced for writer and reader
-            P.part_T[o] = bestT;
-            P.part_lin[o] = bestLin;
-            P.part_ns[o] = bestNs;
+            P.part_T[o] = bestM;
+            P.part_lin[o] = bL;
+            P.part_ns[o] = bE;
         }
     }
 }
@@ -474,12 +498,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void clr_scan_kernel(ScanParams P) {
 // Measured on gfx950 (profiles/): every VALU instruction of this kernel -- FP64 or not -- costs
 // ~4.5 SIMD cycles at 2 waves/SIMD and ~10 at one, so the design minimises instruction count:
 // 1.98 VALU instructions per 64 evaluations in form 2 at J = 16, vs ~6 in the per-site kernel.
-struct alignas(16) ScratchEnt {
-    double e;
-    int ro;   // row * 64
-    int pad;
-};
-
 // -DBMX_PROFILE: s_memtime stamps between the sections of the grouped kernel (diagnostic builds only; the
 // stamps serialise outstanding LDS/scalar loads, so the split is approximate).  Sections: 0 sites between
 // the test sites, 1 zone set-up, 2 per-pass work, 3 products over the near list, 4 ragged-end masks,
@@ -1101,12 +1119,12 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 #endif
 }
 
-// Combine the per-slice winners of a test site; optionally recount nSites of the winning A
-// (the grouped kernel does not carry window sizes).  The count uses the scan's exact predicate:
+// Combine the per-slice winners of a test site, take the one logarithm, and count nSites of the winning A
+// (the scan kernels do not carry window sizes).  The count uses the scan's exact predicate:
 // i in [lo,hi], A*|g_i - t| <= zcut, g_i != t; it is monotone on either side of the test site.
 struct FinalParams {
     const double *part_T; const int32_t *part_lin; const int32_t *part_ns;
-    int nslices, npairs, recount;   // recount != 0: grouped kernel -- parts hold (mantissa, index, clamped exponent + 2^17)
+    int nslices, npairs;            // parts hold (mantissa, linear index, clamped exponent + 2^17) per slice
     int64_t M, N;
     const double *genpos, *A, *test_gen;
     const int64_t *win_lo, *win_hi, *center, *center_hi;
@@ -1120,32 +1138,21 @@ __global__ void finalize_kernel(FinalParams F) {
     if (t >= F.M) return;
     double bT = 0.0;
     int bL = 0x7fffffff, bN = 0;
-    if (F.recount) {
-        double bM = 1.0;
-        int bE = 131072;
-        for (int s = 0; s < F.nslices; ++s) {
-            const double m = F.part_T[(size_t)s * F.M + t];
-            const int L = F.part_lin[(size_t)s * F.M + t];
-            const int e = F.part_ns[(size_t)s * F.M + t];
-            if (L != 0x7fffffff && (e > bE || (e == bE && (m > bM || (m == bM && L < bL))))) {
-                bM = m;
-                bE = e;
-                bL = L;
-            }
-        }
-        if (bL != 0x7fffffff) bT = 2.0 * ((double)(bE - 131072) * LN2 + log(bM));
-    } else
+    double bM = 1.0;
+    int bE = 131072;
     for (int s = 0; s < F.nslices; ++s) {
-        const double T = F.part_T[(size_t)s * F.M + t];
+        const double m = F.part_T[(size_t)s * F.M + t];
         const int L = F.part_lin[(size_t)s * F.M + t];
-        if (T > bT || (T == bT && L < bL)) {
-            bT = T;
+        const int e = F.part_ns[(size_t)s * F.M + t];
+        if (L != 0x7fffffff && (e > bE || (e == bE && (m > bM || (m == bM && L < bL))))) {
+            bM = m;
+            bE = e;
             bL = L;
-            bN = F.part_ns[(size_t)s * F.M + t];
         }
     }
+    if (bL != 0x7fffffff) bT = 2.0 * ((double)(bE - 131072) * LN2 + log(bM));
     const bool none = (bL == 0x7fffffff);
-    if (!none && F.recount) {
+    if (!none) {
         const double A = F.A[bL / F.npairs], tg = F.test_gen[t];
         const int64_t lo = max(F.win_lo[t], (int64_t)0), hi = min(F.win_hi[t], F.N - 1);
         // right of the test position: indices [a0, hi], predicate true on a prefix
@@ -1780,12 +1787,12 @@ int plan_scan(bmx_ctx *c, ScanPlan &pl) {
     const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES && !diag_env("BMX_NO_LDS");   // BMX_NO_LDS: R from L2 (A/B runs)
     if (!fits || c->variant == 1) mom_slots = MOM_SLOTS;
     P.mom_slots = mom_slots;
-    // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3
-    // (windows/s x1000 for J = 16 / 8 / 4 / per-site): stride 1: 2537/-/-/-, 2: 2221/1800, 3: 1899/1706,
-    // 4: 1540/1630/1124, 8: 1073/1299/1031, 16: 733/960/883, 32: 470/693/703, 64: 298/460/540,
-    // 128: 180/307/384/340, 160: -/-/335/338, 200: -/-/316/335 -> J by the median gap between test sites;
-    // beyond ~150 sites the per-site kernel takes over.
-    const int64_t gap_max = diag_env("BMX_DENSE_GAP") ? atoll(diag_env("BMX_DENSE_GAP")) : 150;
+    // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3 at HEAD
+    // (windows/s x1000 for J = 16 / 8 / 4 / per-site; profiles/r02_stride_table.txt): stride 1: 3005/2108/1250/-,
+    // 2: 2585/1989/1229, 3: 2115/1880/1203, 4: 1691/1780/1177, 8: 1146/1391/1075, 16: 755/1014/910, 32: 477/706/720/590,
+    // 48: 341/548/611/575, 64: 276/464/536/569, 128: 140/282/374/523 -> J by the median gap between test sites;
+    // beyond ~56 sites the per-site kernel takes over.
+    const int64_t gap_max = diag_env("BMX_DENSE_GAP") ? atoll(diag_env("BMX_DENSE_GAP")) : 56;
     const bool can_group = c->tests_sorted && c->test_gap <= gap_max && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
     int J = 0;
     // variants (A/B runs): 0 -> J by test-site gap, pairs near / quads mid / power sums far (default);
@@ -1801,7 +1808,7 @@ int plan_scan(bmx_ctx *c, ScanPlan &pl) {
             J = fj;
         }
     }
-    int spb = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : 4);
+    int spb = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : SITE_THREADS / WAVE);   // per-site kernel: >= one test site per wave
     if (J == 16 && spb < 64) spb = 64;
     if (J && diag_env("BMX_SPB")) spb = std::max(4 * J, atoi(diag_env("BMX_SPB")) / (4 * J) * (4 * J));   // experiments
     const bool use_lds = fits && c->variant != 1;
@@ -1830,6 +1837,10 @@ int plan_scan(bmx_ctx *c, ScanPlan &pl) {
         threads = SCAN_THREADS_MAX;
         lds_bytes = (use_lds ? lds + lds_rm : 0) + (size_t)(threads / WAVE) * wave_bytes(mom_slots);
         spb *= 2;
+    }
+    if (!J) {       // per-site kernel: 16 waves, the R slice (if it fits) + 1 KB of scratch list per wave
+        threads = SITE_THREADS;
+        lds_bytes = (use_lds ? lds : 0) + (size_t)(threads / WAVE) * WAVE * sizeof(ScratchEnt);
     }
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return fail(BMX_E_LIMIT, "LDS budget exceeded");
     if (lds_bytes) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1860,7 +1871,7 @@ int launch_range(bmx_ctx *c, ScanPlan &pl, int64_t off, int64_t cnt) {
     HIP_TRY(hipLaunchKernel(pl.fn, dim3((unsigned)blocks), dim3(pl.threads), kargs, pl.lds_bytes, c->stream));
     FinalParams F;
     F.part_T = c->part_T.p; F.part_lin = c->part_lin.p; F.part_ns = c->part_ns.p;
-    F.nslices = c->nslices; F.npairs = c->npairs; F.recount = pl.J ? 1 : 0; F.M = cnt; F.N = c->N;
+    F.nslices = c->nslices; F.npairs = c->npairs; F.M = cnt; F.N = c->N;
     F.genpos = c->genpos.p; F.A = c->d_A; F.test_gen = P.test_gen; F.win_lo = P.win_lo; F.win_hi = P.win_hi;
     F.center = P.center; F.center_hi = P.center_hi; F.zcut = c->zcut;
     F.clr = c->clr.p + off; F.lin = c->lin.p + off; F.nsites = c->nsites.p + off; F.rec = c->rec.p + off;
