@@ -89,6 +89,12 @@ constexpr int SITE_THREADS = 1024;            // per-site kernel: 16 waves per w
 constexpr int LDS_LIMIT_BYTES = 160 * 1024;   // gfx950: 160 KiB per CU
 constexpr int MOM_SLOTS = 254;                // grouped kernel: rows whose far-field sites can be summed as moments
 constexpr int MOM_SLOTS_LDS = 64;             // ... of which this many are used while the R slice occupies the LDS
+#ifndef BMX_PAIR_PREFETCH
+#define BMX_PAIR_PREFETCH (!USE_LDS)      // pair blocks one block ahead: pays for R from global memory only (LDS: 64.22 vs 64.03 ms)
+#endif
+#ifndef BMX_FOLD_RPRE
+#define BMX_FOLD_RPRE (!USE_LDS)          // rows of a fold batch requested with its moments: global memory only (LDS: 64.51 vs 64.03 ms)
+#endif
 #ifndef BMX_FAR_ORDER
 #define BMX_FAR_ORDER 8
 #endif
@@ -258,6 +264,7 @@ struct ScanParams {
     const uint8_t *kmom;
     int row_of_slot[MOM_SLOTS];
     int mom_slots;     // slots per wave allocated in LDS (<= MOM_SLOTS)
+    int wide_tab;      // the global R table has 2^32 bytes or more
     unsigned long long *prof;   // -DBMX_PROFILE builds: cycles per kernel section, summed over waves (else unused)
     float far_bits;    // far_eps * log2(e): exponent-budget bits per far site
     int sites_per_block;
@@ -376,9 +383,14 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_kernel(ScanParams P) {
             lds_R[idx] = P.Rt[(size_t)(idx >> 6) * P.NP + slice * WAVE + (idx & 63)];
         __syncthreads();
     }
-    const double *Rg = P.Rt + slice * WAVE + lane;
-    auto loadR = [&](int rowoff) -> double {                       // rowoff = row * 64
-        return USE_LDS ? lds_R[rowoff + lane] : Rg[(size_t)(rowoff >> 6) * P.NP];
+    // rowoff: index of the row's first value -- row * 64 in the LDS slice, row * NP in the global table (see the grouped kernel)
+    const char *Rb = reinterpret_cast<const char *>(P.Rt + slice * WAVE);
+    const unsigned lane8 = (unsigned)lane * 8u;
+    const int rowmul = USE_LDS ? WAVE : P.wide_tab ? 1 : P.NP;      // tables of 4 GiB and more: rowoff = row, 64-bit arithmetic per load
+    auto loadR = [&](int rowoff) -> double {
+        if (USE_LDS) return lds_R[rowoff + lane];
+        if (P.wide_tab) return *reinterpret_cast<const double *>(Rb + ((size_t)rowoff * P.NP * 8u + lane8));
+        return *reinterpret_cast<const double *>(Rb + ((unsigned)rowoff * 8u + lane8));
     };
     ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_R + (USE_LDS ? P.rows * WAVE : 0)) + wave * WAVE;
 
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_kernel(ScanParams P) {
                     if (cnt) {
                         // lanes outside the window carry alpha = 0; give them the row of an in-window lane so that
                         // 0*R is 0 and never 0*NaN (rows absent from the helper file hold NaN)
-                        const int rowoff = (in ? rraw : __builtin_amdgcn_readlane(rraw, __ffsll((long long)m_in) - 1)) * WAVE;
+                        const int rowoff = (in ? rraw : __builtin_amdgcn_readlane(rraw, __ffsll((long long)m_in) - 1)) * rowmul;
                         scr[lane] = ScratchEnt{in ? exp_neg(z) : 0.0, rowoff, 0};
                         __builtin_amdgcn_wave_barrier();
                         // (no prefetch of the next step's entries, and the entry as an 8-byte + a 4-byte read rather than one 16-byte
@@ -544,9 +556,14 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
             lds_R[total + idx] = P.rowmax[(size_t)slice * P.rows + idx];
         __syncthreads();
     }
-    const double *Rg = P.Rt + slice * WAVE + lane;
-    auto loadR = [&](int rowoff) -> double {                       // rowoff = row * 64
-        return USE_LDS ? lds_R[rowoff + lane] : Rg[(size_t)(rowoff >> 6) * P.NP];
+    // A row is referred to by the index of its first value: row * 64 in the LDS slice, row * NP in the global table (32 bits:
+    // the host checks rows * NP * 8 < 2^31), so that either load is one address addition -- scalar base + 32-bit lane offset
+    // for the global one, not a 64-bit multiply-add per load
+    const char *Rb = reinterpret_cast<const char *>(P.Rt + slice * WAVE);
+    const unsigned lane8 = (unsigned)lane * 8u;
+    const int rowmul = USE_LDS ? WAVE : P.NP;                      // (tables of 4 GiB and more go to the per-site kernel)
+    auto loadR = [&](int rowoff) -> double {
+        return USE_LDS ? lds_R[rowoff + lane] : *reinterpret_cast<const double *>(Rb + ((unsigned)rowoff * 8u + lane8));
     };
     // per-row max |R| of this slice (behind the R slice), then the wave-private scratch: 64 x 16 B
     // then the wave-private scratch (64 x 16 B per wave) and the wave-private moments
@@ -595,7 +612,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
         const bool staged = R_int - L_int <= MID_CAP;
         if (staged && lane_g < R_int - L_int) {
             mid_g[lane_g] = P.genpos[L_int + lane_g];
-            mid_ro[lane_g] = (int)P.row[L_int + lane_g] * WAVE;
+            mid_ro[lane_g] = (int)P.row[L_int + lane_g] * rowmul;
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -632,10 +649,15 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     buf[lane] = alpha;
                     __builtin_amdgcn_wave_barrier();
                 }
+                double Rpre[SP];
+                if (!USE_LDS) {               // R from global memory: all rows of the pass requested at once (lanes without a site: row 0)
+#pragma unroll
+                    for (int s = 0; s < SP; ++s) Rpre[s] = loadR(__builtin_amdgcn_readlane(rowoff, s * J));
+                }
 #pragma unroll
                 for (int s = 0; s < SP; ++s) {
                     if (((m_in >> (s * J)) & ((1ull << J) - 1ull)) == 0ull) continue;
-                    const double R = loadR(__builtin_amdgcn_readlane(rowoff, s * J));
+                    const double R = USE_LDS ? loadR(__builtin_amdgcn_readlane(rowoff, s * J)) : Rpre[s];
                     if (MODE == 1) {
                         const double2 *a2 = reinterpret_cast<const double2 *>(buf + s * J);
 #pragma unroll
@@ -653,19 +675,8 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
             };
 
             // one generic pass over SP sites starting at b, stepping dir; returns "all finished"
-            auto generic_pass = [&](int b, int dir, int lim, bool from_lds) -> bool {
-                const int i = b + dir * sl;
-                const bool inr = dir > 0 ? (i < lim) : (i > lim);
-                // both loads up front: the row is needed only when some site is in a window, but waiting for
-                // the ballot would put two global round trips in series
-                // (two branches, not a select between an LDS and a global address: that would be a flat load)
-                double g = 0.0;
-                int rowoff = 0;
-                if (from_lds) {
-                    if (inr) { g = mid_g[i - L_int]; rowoff = mid_ro[i - L_int]; }
-                } else {
-                    if (inr) { g = P.genpos[i]; rowoff = (int)P.row[i] * WAVE; }
-                }
+            // (site i of the lane, its position and row; lanes with inr = false carry no site)
+            auto generic_core = [&](int i, bool inr, double g, int rowoff, int dir) -> bool {
                 const bool inwin = inr && i >= lo_j && i <= hi_j;
                 const double z = A * fabs(g - tj);
                 const bool in = inwin && (z <= P.zcut) && (g != tj);
@@ -686,6 +697,21 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                     apply_pass(alpha, rowoff, m_in, scr_d);
                 }
                 return __ballot(fin) == ~0ull;
+            };
+            auto generic_pass = [&](int b, int dir, int lim, bool from_lds) -> bool {
+                const int i = b + dir * sl;
+                const bool inr = dir > 0 ? (i < lim) : (i > lim);
+                // both loads up front: the row is needed only when some site is in a window, but waiting for
+                // the ballot would put two global round trips in series
+                // (two branches, not a select between an LDS and a global address: that would be a flat load)
+                double g = 0.0;
+                int rowoff = 0;
+                if (from_lds) {
+                    if (inr) { g = mid_g[i - L_int]; rowoff = mid_ro[i - L_int]; }
+                } else {
+                    if (inr) { g = P.genpos[i]; rowoff = (int)P.row[i] * rowmul; }
+                }
+                return generic_core(i, inr, g, rowoff, dir);
             };
 
             // bulk zone: sites i = base, base+dir, ... ; ok(i) is a prefix property along the walk
@@ -785,7 +811,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             CNT(4, cnt_blk);
                             // lanes past the bulk prefix carry Ev = 0; give them lane 0's (valid, finite)
                             // row so that 0*R is 0 and not 0*NaN from a row absent in the helper file
-                            int rowoff = rraw * WAVE;
+                            int rowoff = rraw * rowmul;
                             rowoff = bulk ? rowoff : __builtin_amdgcn_readlane(rowoff, 0);
                             // lane 0 is the site nearest to the test sites: largest alpha of the pass.
                             // Every factor of this pass lies in [1 - E0, 1 + E0*Rmax].
@@ -845,14 +871,36 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                     }
                                 }
                             }
+                            // (R from global memory: the rows of the NEXT block are requested before this block's arithmetic, as in
+                            // the quad loop -- an L2 round trip per block would otherwise be exposed)
+                            double Rp[BS], ep[BS];
+                            if (BMX_PAIR_PREFETCH && npair > 0) {
+#pragma unroll
+                                for (int u = 0; u < BS; ++u) {
+                                    const ScratchEnt en = scr[u];
+                                    ep[u] = en.e;
+                                    Rp[u] = loadR(en.ro);
+                                }
+                            }
                             for (int l0 = 0; l0 < npair; l0 += BS) {
                                 CNT(3, 1);
                                 spend(span8 * BS / 8);
                                 double v[BS];
+                                if (BMX_PAIR_PREFETCH) {
+#pragma unroll
+                                    for (int u = 0; u < BS; ++u) v[u] = ep[u] * Rp[u];
+#pragma unroll
+                                    for (int u = 0; u < BS; ++u) {
+                                        const ScratchEnt en = scr[min(l0 + BS + u, WAVE - 1)];
+                                        ep[u] = en.e;
+                                        Rp[u] = loadR(en.ro);
+                                    }
+                                } else {
 #pragma unroll
                                 for (int u = 0; u < BS; ++u) {      // lanes >= cnt carry Ev = 0: factor 1
                                     const ScratchEnt en = scr[l0 + u];     // uniform address: LDS broadcast
                                     v[u] = en.e * loadR(en.ro);
+                                }
                                 }
 #pragma unroll
                                 for (int u = 0; u < BS; u += 2) {
@@ -864,7 +912,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             __builtin_amdgcn_wave_barrier();
                             }
                         } else {
-                            int rowoff = rraw * WAVE;
+                            int rowoff = rraw * rowmul;
                             rowoff = bulk ? rowoff : __builtin_amdgcn_readlane(rowoff, 0);
                             const double e0 = readlane_f64(Ev, 0);
                             const double om = 1.0 - e0, op = fma(e0, P.rmax, 1.0);
@@ -938,7 +986,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                         const bool far3 = lane >= nrmax || Er * rowmax[rr] <= 3e-4;     // NaN (absent row): false
                         if (__ballot(far3) == ~0ull) {
                             rag = true;
-                            scr[lane] = ScratchEnt{Er, rr * WAVE, 0};
+                            scr[lane] = ScratchEnt{Er, rr * rowmul, 0};
                             __builtin_amdgcn_wave_barrier();
                         }
                     }
@@ -956,8 +1004,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 #pragma unroll
                     for (int k = 0; k < FAR_ORDER; ++k) p[k] = 0.0;
                     if (nfar_tot) {
-                    auto fold = [&](const double (&m)[FAR_ORDER], int slot) {
-                        const double R = loadR(P.row_of_slot[slot] * WAVE);
+                    auto fold = [&](const double (&m)[FAR_ORDER], const double R) {
                         const double R2 = R * R, R3 = R2 * R, R4 = R2 * R2;
                         p[0] = fma(m[0], R, p[0]);
                         p[1] = fma(m[1], R2, p[1]);
@@ -985,13 +1032,18 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                         double m[FAR_ORDER];
 #pragma unroll
                         for (int k = 0; k < FAR_ORDER; ++k) m[k] = readlane_f64(x, k);
-                        if (m[0] != 0.0) fold(m, 0);
+                        if (m[0] != 0.0) fold(m, loadR(P.row_of_slot[0] * rowmul));
                     }
                     // the other slots, four at a time: all LDS reads of a batch are in flight together
                     CNT(10, kmom);
                     constexpr int FB = BMX_FOLD_BATCH;                       // slots per batch: their LDS reads are in flight together
                     for (int s0 = 1; s0 < kmom; s0 += FB) {
                         double2 m2[FB][FAR_ORDER / 2];
+                        double Rs[FB];
+                        if (BMX_FOLD_RPRE) {      // the batch's rows are requested together with the moments
+#pragma unroll
+                            for (int u = 0; u < FB; ++u) Rs[u] = loadR(P.row_of_slot[min(s0 + u, MOM_SLOTS - 1)] * rowmul);
+                        }
 #pragma unroll
                         for (int u = 0; u < FB; ++u) {
                             double2 *mp = reinterpret_cast<double2 *>(mom + (s0 + u + MOM_COPIES - 1) * FAR_ORDER);
@@ -1008,7 +1060,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                 m[2 * q] = m2[u][q].x;
                                 m[2 * q + 1] = m2[u][q].y;
                             }
-                            fold(m, min(s0 + u, MOM_SLOTS - 1));
+                            fold(m, BMX_FOLD_RPRE ? Rs[u] : loadR(P.row_of_slot[min(s0 + u, MOM_SLOTS - 1)] * rowmul));
                         }
                     }
                     // ready for the next zone: one lane-parallel sweep over the slots that may have been used
@@ -1022,6 +1074,12 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 #pragma unroll
                     for (int k = 0; k < FAR_ORDER; ++k) p[k] *= FAR_W[k];
                     int l = 0;
+                    double rag_e = 0.0, rag_R = 0.0;
+                    if (rag) {
+                        const ScratchEnt en = scr[0];
+                        rag_e = en.e;
+                        rag_R = loadR(en.ro);
+                    }
 #pragma unroll
                     for (int w = 0; w < J; w += 2) {
                         // test sites in pairs: the two exps of a pair are interleaved chains (exp_neg2), and the pair's
@@ -1033,8 +1091,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             if (rag) {
                                 const int nj = __builtin_amdgcn_readlane(nrag_v, j);
                                 for (; l < nj; ++l) {                         // the ragged sites that window j adds
-                                    const ScratchEnt en = scr[l];
-                                    const double v = en.e * loadR(en.ro), v2 = v * v;
+                                    const double v = rag_e * rag_R, v2 = v * v;
+                                    const ScratchEnt en = scr[min(l + 1, WAVE - 1)];      // the next site's entry and row: one step ahead
+                                    rag_e = en.e;
+                                    rag_R = loadR(en.ro);
                                     p[0] += v;
                                     p[1] = fma(v2, 0.5, p[1]);
                                     p[2] = fma(v2 * v, 0.3333333333333333, p[2]);
@@ -1787,13 +1847,14 @@ int plan_scan(bmx_ctx *c, ScanPlan &pl) {
     const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES && !diag_env("BMX_NO_LDS");   // BMX_NO_LDS: R from L2 (A/B runs)
     if (!fits || c->variant == 1) mom_slots = MOM_SLOTS;
     P.mom_slots = mom_slots;
+    P.wide_tab = (size_t)c->rows * c->NP * sizeof(double) >= ((size_t)1 << 32) ? 1 : 0;
     // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3 at HEAD
     // (windows/s x1000 for J = 16 / 8 / 4 / per-site; profiles/r02_stride_table.txt): stride 1: 3005/2108/1250/-,
     // 2: 2585/1989/1229, 3: 2115/1880/1203, 4: 1691/1780/1177, 8: 1146/1391/1075, 16: 755/1014/910, 32: 477/706/720/590,
     // 48: 341/548/611/575, 64: 276/464/536/569, 128: 140/282/374/523 -> J by the median gap between test sites;
     // beyond ~56 sites the per-site kernel takes over.
     const int64_t gap_max = diag_env("BMX_DENSE_GAP") ? atoll(diag_env("BMX_DENSE_GAP")) : 56;
-    const bool can_group = c->tests_sorted && c->test_gap <= gap_max && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191;
+    const bool can_group = c->tests_sorted && c->test_gap <= gap_max && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191 && !P.wide_tab;
     int J = 0;
     // variants (A/B runs): 0 -> J by test-site gap, pairs near / quads mid / power sums far (default);
     //           3 -> J=8, 4 -> J=4 (same form); 10/11 -> J=16/8 without the power sums (exact products);
