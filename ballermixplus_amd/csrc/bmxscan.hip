@@ -109,6 +109,9 @@ constexpr int MOM_COPIES = BMX_MOM_COPIES;                 // copies of the most
 #ifndef BMX_FOLD_BATCH
 #define BMX_FOLD_BATCH 2
 #endif
+constexpr int SCR_CAP = 80;                   // grouped kernel: entries of a wave's scratch list: up to 64 pending + 16 neutral ones (padding of the
+                                              // last block of 4 or 8 and what the block loops read one block ahead -- R from global memory must
+                                              // never see a stale row reference)
 constexpr int MID_CAP = 32;                   // grouped kernel: sites between the test sites of a group staged in LDS (12 B each)
 constexpr int FAR_CAP = 8192;                 // ... at most this many sites per zone (exponent budget: 8192 * 0.05 * 1.49 bits < 1000)
 constexpr double LN2 = 0.693147180559945309417232121458;
@@ -570,11 +573,11 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
     const int rows_pad = (P.rows + 1) & ~1;
     const double *rowmax = USE_LDS ? lds_R + P.rows * WAVE : P.rowmax + (size_t)slice * P.rows;
     double *lds_tail = lds_R + (USE_LDS ? P.rows * WAVE + rows_pad : 0);
-    ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_tail) + wave * WAVE;
+    ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_tail) + wave * SCR_CAP;
     const int mom_len = (P.mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER;   // slot 0 in MOM_COPIES copies, slots 1.., 3 spare
-    double *mom = lds_tail + (blockDim.x / WAVE) * WAVE * 2 + wave * mom_len;
+    double *mom = lds_tail + (blockDim.x / WAVE) * SCR_CAP * 2 + wave * mom_len;
     // ... and the sites between the group's test sites (position, row * 64): read by the generic passes of all nA iterations
-    double *mid_base = lds_tail + (blockDim.x / WAVE) * (WAVE * 2 + mom_len);
+    double *mid_base = lds_tail + (blockDim.x / WAVE) * (SCR_CAP * 2 + mom_len);
     if (MODE_ == 3) {
         for (int idx = lane; idx < mom_len; idx += WAVE) mom[idx] = 0.0;
         __builtin_amdgcn_wave_barrier();
@@ -729,23 +732,36 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                 double g_nx = P.genpos[min(max(i, 0), N - 1)];
                 int r_nx = (int)P.row[min(max(i, 0), N - 1)];
                 int nfar_tot = 0;                                  // far-field sites of this zone (FARSUM)
+                // MODE 1: the near list is carried from pass to pass -- entries pending in scr[0 .. fill), worked off in blocks
+                // of four only when the next pass would not fit behind them or the zone has ended, so the padding of the last
+                // block and the set-up of the block loops are paid once per ~60 near sites, not once per pass (~15)
+                int fill = 0, pend_np = 0, pend_hi = 0, pend_lo = 0, pad_ro = 0;
+                bool ended = false;
+                auto rank = [&](unsigned long long m) {
+                    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                };
                 PROF_MARK(1);
                 while (true) {
+                    int cnt = 0, cnt_blk = 0, inx = i;
+                    bool nearl = false;
+                    double Ev = 0.0;
+                    int rraw = 0;
+                    if (!ended) {
                     const bool ok = dir > 0 ? (i <= hi_min) : (i >= lo_max);
                     const double g = g_nx;
-                    const int rraw = r_nx;
-                    const int inx = i + dir * WAVE;
+                    rraw = r_nx;
+                    inx = i + dir * WAVE;
                     g_nx = P.genpos[min(max(inx, 0), N - 1)];
                     r_nx = (int)P.row[min(max(inx, 0), N - 1)];
                     const bool bulk = ok && (A * fabs(g - tfar) <= P.zcut);
                     const unsigned long long mb = __ballot(bulk);
-                    const int cnt = __popcll(mb);
+                    cnt = __popcll(mb);
                     CNT(13, 1);
                     if (cnt) {
                         CNT(0, 1);
                         CNT(14, cnt);
-                        const double Ev = bulk ? exp_neg(A * fabs(g - tnear)) : 0.0;
-                        int cnt_blk = cnt;                              // sites left to the block loops
+                        Ev = bulk ? exp_neg(A * fabs(g - tnear)) : 0.0;
+                        cnt_blk = cnt;                                  // sites left to the block loops
                         if (MODE == 1) {
                             // FARSUM.  A site is FAR when alpha*|R| <= far_eps for every pair of the slice and every
                             // test site (alpha = E F <= E) and its row is one of the kmom most frequent rows of the
@@ -753,9 +769,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             //   sum_i log1p(F v_i) = sum_k (-1)^(k+1) F^k/k * sum_rows R[row]^k M_k[row],  M_k = sum_i E_i^k,
                             // so the pass only adds E, E^2, .. E^8 to the row's moments in LDS -- lane-parallel over
                             // the sites, nothing per pair -- and the zone's end folds the moments into the product.
-                            // Far lanes leave a neutral entry (E = 0) behind the near list of the scratch.
                             bool moml = false;
-                            int pos = lane;
                             if (FARSUM && kmom) {
                                 const double ri = rowmax[rraw];                 // row's max |R|, its moment slot in the low byte
                                 const int slot = __double2loint(ri) & 0xff;
@@ -794,34 +808,44 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                         }
                                     }
                                     PROF_MARK(11);
-                                    const unsigned long long mn = mb & ~mm;
-                                    auto rank = [&](unsigned long long m) {
-                                        return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                                    };
-                                    // scratch: [near | far lanes (E = 0) | lanes past the bulk prefix]
-                                    pos = moml ? cnt - nfar + rank(mm) : bulk ? rank(mn) : lane;
                                     nfar_tot += nfar;
                                     cnt_blk = cnt - nfar;
                                     CNT(5, nfar);
                                 }
                             }
+                            nearl = bulk && !moml;
                             PROF_MARK(2);
-                            if (cnt_blk > 0) {                          // else every site of the pass went to the moments
-                            CNT(1, 1);
-                            CNT(4, cnt_blk);
-                            // lanes past the bulk prefix carry Ev = 0; give them lane 0's (valid, finite)
-                            // row so that 0*R is 0 and not 0*NaN from a row absent in the helper file
+                        } else {
                             int rowoff = rraw * rowmul;
                             rowoff = bulk ? rowoff : __builtin_amdgcn_readlane(rowoff, 0);
-                            // lane 0 is the site nearest to the test sites: largest alpha of the pass.
-                            // Every factor of this pass lies in [1 - E0, 1 + E0*Rmax].
                             const double e0 = readlane_f64(Ev, 0);
                             const double om = 1.0 - e0, op = fma(e0, P.rmax, 1.0);
                             const int lowbits = 1024 - ((__double2hiint(om) >> 20) & 0x7ff);
                             const int hibits = ((__double2hiint(op) >> 20) & 0x7ff) - 1022;
                             const int span8 = 8 * min(max(hibits, lowbits), 125);
-                            scr[pos] = ScratchEnt{moml ? 0.0 : Ev, rowoff, 0};
+                            for (int l0 = 0; l0 < cnt; l0 += 8) {
+                                spend(span8);
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) {
+                                    const int l = l0 + u;           // lanes >= cnt carry Ev = 0: factor 1
+                                    const double v = readlane_f64(Ev, l) * loadR(__builtin_amdgcn_readlane(rowoff, l));
+#pragma unroll
+                                    for (int j = 0; j < J; ++j) acc[j] *= fma(F[j], v, 1.0);
+                                }
+                            }
+                        }
+                    }
+                    }
+                    if (MODE == 1) {
+                        if (fill > 0 && (ended || fill + cnt_blk > WAVE - 4)) {
+                            CNT(1, 1);
+                            CNT(4, fill);
+                            // neutral entries (E = 0, the row of a site of the zone: 0*R is 0, not 0*NaN from a row absent in the
+                            // helper file) behind the list: the padding of the last block and what the loops read one block ahead
+                            if (lane < 16) scr[fill + lane] = ScratchEnt{0.0, pad_ro, 0};
                             __builtin_amdgcn_wave_barrier();
+                            // every factor of the pending sites lies in [1 - E0, 1 + E0*Rmax], E0 the largest alpha among them
+                            const int span8 = 8 * min(max(pend_hi, pend_lo), 125);
                             constexpr int BS = J >= 16 ? 4 : 8;        // sites per unrolled block
                             // Sites with alpha <= 1/2 (factors >= 1/2: the expanded product is well conditioned) are
                             // taken FOUR per step:
@@ -829,21 +853,20 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                             // e_k = elementary symmetric polynomials of v_1..v_4 shared by all J test sites:
                             // 4 FMA + 1 MUL per test site per four sites.  The near list is ordered by distance, so the
                             // entries with E > 1/2 are a prefix: they go two per step (below), rounded up to whole blocks.
-                            const int npair = !QUAD ? cnt_blk
-                                                    : min(cnt_blk, (__popcll(__ballot(bulk && !moml && Ev > 0.5)) + BS - 1) & ~(BS - 1));
-                            const int span8q = 8 * min(max(hibits, 2), 125);
+                            const int npair = !QUAD ? fill : min(fill, (pend_np + BS - 1) & ~(BS - 1));
+                            const int span8q = 8 * min(max(pend_hi, 2), 125);
                             PROF_MARK(9);
-                            if (QUAD && npair < cnt_blk) {
+                            if (QUAD && npair < fill) {
                                 // the R rows of the NEXT four sites are requested before this block's arithmetic, so the
                                 // two dependent LDS round trips (list entry -> row) of a block hide under the previous one
                                 double Rn[4], en_e[4];
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
-                                    const ScratchEnt en = scr[min(npair + u, WAVE - 1)];
+                                    const ScratchEnt en = scr[min(npair + u, SCR_CAP - 1)];
                                     en_e[u] = en.e;
                                     Rn[u] = loadR(en.ro);
                                 }
-                                for (int l0 = npair; l0 < cnt_blk; l0 += 4) {
+                                for (int l0 = npair; l0 < fill; l0 += 4) {
                                     CNT(2, 1);
                                     spend(span8q / 2);
                                     double v[4];
@@ -851,7 +874,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                     for (int u = 0; u < 4; ++u) v[u] = en_e[u] * Rn[u];
 #pragma unroll
                                     for (int u = 0; u < 4; ++u) {
-                                        const ScratchEnt en = scr[min(l0 + 4 + u, WAVE - 1)];
+                                        const ScratchEnt en = scr[min(l0 + 4 + u, SCR_CAP - 1)];
                                         en_e[u] = en.e;
                                         Rn[u] = loadR(en.ro);
                                     }
@@ -891,7 +914,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                     for (int u = 0; u < BS; ++u) v[u] = ep[u] * Rp[u];
 #pragma unroll
                                     for (int u = 0; u < BS; ++u) {
-                                        const ScratchEnt en = scr[min(l0 + BS + u, WAVE - 1)];
+                                        const ScratchEnt en = scr[min(l0 + BS + u, SCR_CAP - 1)];
                                         ep[u] = en.e;
                                         Rp[u] = loadR(en.ro);
                                     }
@@ -910,30 +933,31 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                 }
                             }
                             __builtin_amdgcn_wave_barrier();
+                            fill = 0;
+                            pend_np = 0;
+                        }
+                        PROF_MARK(3);
+                        if (ended) break;
+                        if (cnt_blk > 0) {
+                            if (fill == 0) {
+                                // lane 0 is the site of the pass nearest to the test sites: the largest alpha of everything pending
+                                const double e0 = readlane_f64(Ev, 0);
+                                const double om = 1.0 - e0, op = fma(e0, P.rmax, 1.0);
+                                pend_lo = 1024 - ((__double2hiint(om) >> 20) & 0x7ff);
+                                pend_hi = ((__double2hiint(op) >> 20) & 0x7ff) - 1022;
+                                pad_ro = __builtin_amdgcn_readlane(rraw, 0) * rowmul;
                             }
-                        } else {
-                            int rowoff = rraw * rowmul;
-                            rowoff = bulk ? rowoff : __builtin_amdgcn_readlane(rowoff, 0);
-                            const double e0 = readlane_f64(Ev, 0);
-                            const double om = 1.0 - e0, op = fma(e0, P.rmax, 1.0);
-                            const int lowbits = 1024 - ((__double2hiint(om) >> 20) & 0x7ff);
-                            const int hibits = ((__double2hiint(op) >> 20) & 0x7ff) - 1022;
-                            const int span8 = 8 * min(max(hibits, lowbits), 125);
-                            for (int l0 = 0; l0 < cnt; l0 += 8) {
-                                spend(span8);
-#pragma unroll
-                                for (int u = 0; u < 8; ++u) {
-                                    const int l = l0 + u;           // lanes >= cnt carry Ev = 0: factor 1
-                                    const double v = readlane_f64(Ev, l) * loadR(__builtin_amdgcn_readlane(rowoff, l));
-#pragma unroll
-                                    for (int j = 0; j < J; ++j) acc[j] *= fma(F[j], v, 1.0);
-                                }
-                            }
+                            const unsigned long long mn = __ballot(nearl);
+                            if (nearl) scr[fill + rank(mn)] = ScratchEnt{Ev, rraw * rowmul, 0};
+                            if (QUAD) pend_np += __popcll(__ballot(nearl && Ev > 0.5));
+                            fill += cnt_blk;
                         }
                     }
-                    PROF_MARK(3);
                     base += dir * cnt;
-                    if (cnt < WAVE) break;
+                    if (cnt < WAVE) {
+                        if (MODE != 1) break;
+                        ended = true;                                  // one more turn: works off what is pending
+                    }
                     i = inx;
                 }
                 PROF_MARK(2);
@@ -1837,7 +1861,7 @@ int plan_scan(bmx_ctx *c, ScanPlan &pl) {
     // too large for LDS anyway (many sample sizes: the sites spread over many rows), all MOM_SLOTS
     int mom_slots = MOM_SLOTS_LDS;
     auto wave_bytes = [&](int slots) {
-        return WAVE * sizeof(ScratchEnt) + (size_t)(slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double) + (size_t)MID_CAP * 12;
+        return SCR_CAP * sizeof(ScratchEnt) + (size_t)(slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double) + (size_t)MID_CAP * 12;
     };
     auto lds_need = [&](int slots) {
         return lds + (size_t)(c->rows + 2) * sizeof(double) + (size_t)(SCAN_THREADS_MAX / WAVE) * wave_bytes(slots);
