@@ -95,6 +95,9 @@ constexpr int MOM_SLOTS_LDS = 64;             // ... of which this many are used
 #ifndef BMX_FOLD_RPRE
 #define BMX_FOLD_RPRE (!USE_LDS)          // rows of a fold batch requested with its moments: global memory only (LDS: 64.51 vs 64.03 ms)
 #endif
+#ifndef BMX_MIDTRI
+#define BMX_MIDTRI 1
+#endif
 #ifndef BMX_FAR_ORDER
 #define BMX_FAR_ORDER 8
 #endif
@@ -543,6 +546,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
     constexpr bool QUAD = (MODE_ >= 2);                             // MODE_ 2 = MODE 1 + quads in far passes
     constexpr bool FARSUM = (MODE_ == 3);                           // MODE_ 3 = MODE 2 + far-field moments
     constexpr int MODE = MODE_ ? 1 : 0;
+    constexpr bool MIDTRI = (MODE_ >= 2) && BMX_MIDTRI;           // dense test sets: the J x J triangle between the test sites in pair form
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform: group-level scalars live in SGPRs
     const int slice = blockIdx.x % P.nslices;
@@ -618,6 +622,19 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
             mid_ro[lane_g] = (int)P.row[L_int + lane_g] * rowmul;
         }
         __builtin_amdgcn_wave_barrier();
+        // Dense test sets: the sites between the test sites ARE the J test sites (site k at t_k, positions strictly
+        // increasing, every site inside every window's index bounds).  Then alpha_ij = exp(-A|t_i - t_j|) separates into
+        // G_i H_j (j < i) and H_i G_j (j > i), G_k = exp(-A(t_k - t_0)), H_k = 1/G_k, and the triangle of (site, test site)
+        // pairs runs in the pair form of the bulk loops instead of generic passes (see the A loop).
+        bool mid_tri = false;
+        if (MIDTRI) {
+            const bool same = staged && (R_int - L_int == J) && nvalid == J && lo_max <= L_int && hi_min >= R_int - 1;
+            if (same) {
+                const double gm = mid_g[jl_g];
+                const double tprev = __shfl_up(tj, 1);
+                mid_tri = __ballot(!(gm == tj && (jl_g == 0 || tj > tprev))) == 0ull;
+            }
+        }
 
         // running best per test site: key = (clamped exponent + 2^17) << 13 | iA  (iA = 8191: none yet)
         double acc[J], bestM[J];
@@ -1148,7 +1165,54 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 
             // sites between / at the test sites (and any part of the windows not covered by bulk)
             PROF_MARK(8);
-            for (int b = L_int; b < R_int; b += SP) generic_pass(b, +1, R_int, staged);
+            if (MIDTRI && mid_tri && A * (tL - t0) <= P.zcut) {
+                // every pair is inside the cut-off (|t_i - t_j| <= tL - t0; FP subtraction and multiplication are monotone)
+                const double xk = A * (tj - t0);
+                double Gk, Hk;
+                exp_neg2(xk, -xk, Gk, Hk);
+                const int ro_k = mid_ro[jl];
+                // each test site meets the other J - 1 sites once; every factor lies in [1 - alpha, 1 + alpha Rmax], alpha < 1
+                spend((J - 1) * span_generic);
+                double Fs[J];
+                // sites i reach the test sites j < i:  alpha_ij = H_j G_i
+#pragma unroll
+                for (int j = 0; j < J; ++j) Fs[j] = readlane_f64(Hk, j);
+                if (lane < J) scr[lane] = ScratchEnt{Gk, ro_k, 0};
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < J; i += 2) {
+                    const ScratchEnt en0 = scr[i], en1 = scr[i + 1];
+                    const double v1 = en1.e * loadR(en1.ro);
+                    if (i > 0) {
+                        const double v0 = en0.e * loadR(en0.ro);
+                        const double sv = v0 + v1, qv = v0 * v1;
+#pragma unroll
+                        for (int j = 0; j < i; ++j) acc[j] *= fma(Fs[j], fma(Fs[j], qv, sv), 1.0);
+                    }
+                    acc[i] *= fma(Fs[i], v1, 1.0);                    // test site i: site i + 1 only
+                }
+                __builtin_amdgcn_wave_barrier();
+                // sites i reach the test sites j > i:  alpha_ij = G_j H_i
+#pragma unroll
+                for (int j = 0; j < J; ++j) Fs[j] = readlane_f64(Gk, j);
+                if (lane < J) scr[lane] = ScratchEnt{Hk, ro_k, 0};
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < J; i += 2) {
+                    const ScratchEnt en0 = scr[i], en1 = scr[i + 1];
+                    const double v0 = en0.e * loadR(en0.ro);
+                    if (i + 2 < J) {
+                        const double v1 = en1.e * loadR(en1.ro);
+                        const double sv = v0 + v1, qv = v0 * v1;
+#pragma unroll
+                        for (int j = i + 2; j < J; ++j) acc[j] *= fma(Fs[j], fma(Fs[j], qv, sv), 1.0);
+                    }
+                    acc[i + 1] *= fma(Fs[i + 1], v0, 1.0);            // test site i + 1: site i only
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                for (int b = L_int; b < R_int; b += SP) generic_pass(b, +1, R_int, staged);
+            }
             PROF_MARK(0);
             // right side
             int b = bulk_zone(R_int, +1, tL, t0);
