@@ -1,3 +1,4 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-for s in 64 128 200; do python scripts/kexp.py --step $s --windows 65536 --reps 2 --tag default 2>&1 | cut -c1-120; python scripts/kexp.py --step $s --windows 65536 --reps 2 --variant 2 --tag exact 2>&1 | cut -c1-120; done
-python scripts/kexp.py --snps 4000000 --step 200 --windows 65536 --reps 2 --tag default4M 2>&1 | cut -c1-120
+bash scripts/pmc_collect.sh c3 --config 3 > /dev/null 2>&1
+bash scripts/pmc_collect.sh c4 --config 4 > /dev/null 2>&1
+bash scripts/pmc_collect.sh c5 --config 5 > /dev/null 2>&1
+for t in c3 c4 c5; do echo "=== $t"; cat gpurun_out/r02/$t/summary.txt; done
