@@ -152,3 +152,7 @@ def main(argv=None):
 
 if __name__ == '__main__':
     main()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if os.environ.get('BMX_FAST_EXIT', '1') != '0':       # see BalLeRMixPlus_amd.py
+        os._exit(0)
