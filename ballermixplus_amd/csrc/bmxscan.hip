@@ -112,6 +112,7 @@ constexpr int MOM_COPIES = BMX_MOM_COPIES;                 // copies of the most
 #ifndef BMX_FOLD_BATCH
 #define BMX_FOLD_BATCH 2
 #endif
+constexpr int SITE_SCR = 72;                  // per-site kernel: two lists of at most 64 sites, each padded to a multiple of four
 constexpr int SCR_CAP = 80;                   // grouped kernel: entries of a wave's scratch list: up to 64 pending + 16 neutral ones (padding of the
                                               // last block of 4 or 8 and what the block loops read one block ahead -- R from global memory must
                                               // never see a stale row reference)
@@ -269,6 +270,7 @@ struct ScanParams {
     const double *rowmax;
     const uint8_t *kmom;
     int row_of_slot[MOM_SLOTS];
+    int row0;          // per-site kernel: the most frequent row of the data (-1: none)
     int mom_slots;     // slots per wave allocated in LDS (<= MOM_SLOTS)
     int wide_tab;      // the global R table has 2^32 bytes or more
     unsigned long long *prof;   // -DBMX_PROFILE builds: cycles per kernel section, summed over waves (else unused)
@@ -398,7 +400,15 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_kernel(ScanParams P) {
         if (P.wide_tab) return *reinterpret_cast<const double *>(Rb + ((size_t)rowoff * P.NP * 8u + lane8));
         return *reinterpret_cast<const double *>(Rb + ((unsigned)rowoff * 8u + lane8));
     };
-    ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_R + (USE_LDS ? P.rows * WAVE : 0)) + wave * WAVE;
+    ScratchEnt *scr = reinterpret_cast<ScratchEnt *>(lds_R + (USE_LDS ? P.rows * WAVE : 0)) + wave * SITE_SCR;
+    // The most frequent row of the data (substitutions: ~70 % of the sites) stays in a register pair: its sites go through a list
+    // of their own and need no R read at all -- this kernel is bound by LDS bandwidth (512 B of R per site and slice), not by
+    // arithmetic, and by L2 bandwidth when the table does not fit the LDS.
+    const int row0 = P.row0;
+    const double R0 = row0 >= 0 ? loadR(row0 * rowmul) : 0.0;
+    auto rank = [&](unsigned long long m) {
+        return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    };
 
     const int64_t t_begin = chunk * P.sites_per_block;
     const int64_t t_end = min(t_begin + (int64_t)P.sites_per_block, P.M);
@@ -431,21 +441,37 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_kernel(ScanParams P) {
                     const bool in = valid && (z <= P.zcut) && (g != tg);
                     const bool beyond = valid && (z > P.zcut);
                     const unsigned long long m_in = __ballot(in);
-                    const int cnt = m_in ? 64 - __clzll((long long)m_in) : 0;
-                    if (cnt) {
-                        // lanes outside the window carry alpha = 0; give them the row of an in-window lane so that
-                        // 0*R is 0 and never 0*NaN (rows absent from the helper file hold NaN)
-                        const int rowoff = (in ? rraw : __builtin_amdgcn_readlane(rraw, __ffsll((long long)m_in) - 1)) * rowmul;
-                        scr[lane] = ScratchEnt{in ? exp_neg(z) : 0.0, rowoff, 0};
+                    if (m_in != 0ull) {
+                        // two lists in the scratch: the sites of row0 at [0, n0), the others from n0r = n0 rounded up to 4 on,
+                        // each padded to a multiple of four with neutral entries (alpha = 0; the row of a site of the window, so
+                        // that 0*R is 0 and never 0*NaN: rows absent from the helper file hold NaN)
+                        const bool is0 = in && rraw == row0;
+                        const unsigned long long m0 = __ballot(is0), m1 = m_in & ~m0;
+                        const int n0 = __popcll(m0), n1 = __popcll(m1), n0r = (n0 + 3) & ~3;
+                        const int pad_ro = __builtin_amdgcn_readlane(rraw, __ffsll((long long)m_in) - 1) * rowmul;
+                        if (in) scr[is0 ? rank(m0) : n0r + rank(m1)] = ScratchEnt{exp_neg(z), rraw * rowmul, 0};
+                        if (lane < n0r - n0) scr[n0 + lane] = ScratchEnt{0.0, pad_ro, 0};
+                        if (lane < 3) scr[n0r + n1 + lane] = ScratchEnt{0.0, pad_ro, 0};
                         __builtin_amdgcn_wave_barrier();
+                        for (int l = 0; l < n0; l += 4) {
+                            double f[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) f[u] = fma(scr[l + u].e, R0, 1.0);       // uniform address: LDS broadcast
+                            acc *= (f[0] * f[1]) * (f[2] * f[3]);
+                            since += 4;
+                            if (since + 4 > P.renorm_every) {
+                                renorm(acc, E);
+                                since = 0;
+                            }
+                        }
                         // (no prefetch of the next step's entries, and the entry as an 8-byte + a 4-byte read rather than one 16-byte
                         // read: with 8 waves per SIMD the LDS round trips are covered by the other waves; both variants were
                         // measured slower, by 17 % and 4 %)
-                        for (int l = 0; l < cnt; l += 4) {
+                        for (int l = n0r; l < n0r + n1; l += 4) {
                             double f[4];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                const ScratchEnt en = scr[min(l + u, WAVE - 1)];      // uniform address: LDS broadcast
+                                const ScratchEnt en = scr[l + u];
                                 f[u] = fma(en.e, loadR(en.ro), 1.0);
                             }
                             acc *= (f[0] * f[1]) * (f[2] * f[3]);
@@ -1465,6 +1491,7 @@ struct bmx_ctx {
     bool wide_rows = false;
     DevBuf<uint8_t> kmom;        // far-field moment slots that pay at each A (set_sites)
     int row_of_slot[MOM_SLOTS] = {0};
+    int nslots = 0;              // rows ranked by frequency: row_of_slot[0 .. nslots)
     unsigned long long *d_prof = nullptr;   // -DBMX_PROFILE / -DBMX_COUNT builds
     // tests
     bool has_tests = false;
@@ -1809,6 +1836,7 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
             nslots = (int)k + 1;
         }
         for (int k = nslots; k < MOM_SLOTS; k++) c->row_of_slot[k] = nslots ? c->row_of_slot[0] : 0;
+        c->nslots = nslots;
         const int kcap = diag_env("BMX_MOM_SLOTS") ? std::min(std::max(atoi(diag_env("BMX_MOM_SLOTS")), 0), MOM_SLOTS) : MOM_SLOTS;
         const double range = genpos[N - 1] - genpos[0];
         std::vector<uint8_t> km((size_t)c->nA, 0);
@@ -1935,6 +1963,7 @@ int plan_scan(bmx_ctx *c, ScanPlan &pl) {
     const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES && !diag_env("BMX_NO_LDS");   // BMX_NO_LDS: R from L2 (A/B runs)
     if (!fits || c->variant == 1) mom_slots = MOM_SLOTS;
     P.mom_slots = mom_slots;
+    P.row0 = c->nslots > 0 ? c->row_of_slot[0] : -1;
     P.wide_tab = (size_t)c->rows * c->NP * sizeof(double) >= ((size_t)1 << 32) ? 1 : 0;
     // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3 at HEAD
     // (windows/s x1000 for J = 16 / 8 / 4 / per-site; profiles/r02_stride_table.txt): stride 1: 3005/2108/1250/-,
@@ -1989,7 +2018,7 @@ int plan_scan(bmx_ctx *c, ScanPlan &pl) {
     }
     if (!J) {       // per-site kernel: 16 waves, the R slice (if it fits) + 1 KB of scratch list per wave
         threads = SITE_THREADS;
-        lds_bytes = (use_lds ? lds : 0) + (size_t)(threads / WAVE) * WAVE * sizeof(ScratchEnt);
+        lds_bytes = (use_lds ? lds : 0) + (size_t)(threads / WAVE) * SITE_SCR * sizeof(ScratchEnt);
     }
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return fail(BMX_E_LIMIT, "LDS budget exceeded");
     if (lds_bytes) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
