@@ -98,6 +98,9 @@ constexpr int MOM_SLOTS_LDS = 64;             // ... of which this many are used
 #ifndef BMX_MIDTRI
 #define BMX_MIDTRI 1
 #endif
+#ifndef BMX_PRIV01
+#define BMX_PRIV01 1
+#endif
 #ifndef BMX_FAR_ORDER
 #define BMX_FAR_ORDER 8
 #endif
@@ -775,6 +778,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                 double g_nx = P.genpos[min(max(i, 0), N - 1)];
                 int r_nx = (int)P.row[min(max(i, 0), N - 1)];
                 int nfar_tot = 0;                                  // far-field sites of this zone (FARSUM)
+                double m1p = 0.0, m2p = 0.0;                       // lane-private first and second moments of slot 0
                 // MODE 1: the near list is carried from pass to pass -- entries pending in scr[0 .. fill), worked off in blocks
                 // of four only when the next pass would not fit behind them or the zone has ended, so the padding of the last
                 // block and the set-up of the block loops are paid once per ~60 near sites, not once per pass (~15)
@@ -829,8 +833,15 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                                         // ds_add_f64 costs ~0.65 FMA slots per active lane (scripts/ubench_lds_atomic), so a
                                         // lane only adds the powers it needs: x^k/k < 2e-15 is dropped (x = E * rowmax >= |F v|)
                                         const double E2 = Ev * Ev;
-                                        atomicAdd(mr, Ev);
-                                        atomicAdd(mr + 1, E2);
+                                        if (BMX_PRIV01 && slot == 0) {
+                                            // the most frequent row (70 % of the sites): first and second moments -- the two every far
+                                            // site adds -- in two registers of the lane, joined to the LDS copies at the fold
+                                            m1p += Ev;
+                                            m2p += E2;
+                                        } else {
+                                            atomicAdd(mr, Ev);
+                                            atomicAdd(mr + 1, E2);
+                                        }
                                         if (xr > 1.8e-5) {
                                             const double E3 = E2 * Ev;
                                             atomicAdd(mr + 2, E3);
@@ -1093,6 +1104,18 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
                         if (lane < MOM_COPIES * FAR_ORDER) {
                             x = mom[lane];
                             mom[lane] = 0.0;                              // ready for the next zone
+                        }
+                        if (BMX_PRIV01) {
+                            // lane = copy * 8 + order: the private sums are first added up over each group of eight lanes, then
+                            // join the copies' first (order 0) and second (order 1) entries; the loop below sums over the copies
+                            double y1 = m1p, y2 = m2p;
+#pragma unroll
+                            for (int off = 1; off < FAR_ORDER; off <<= 1) {
+                                y1 += __shfl_xor(y1, off);
+                                y2 += __shfl_xor(y2, off);
+                            }
+                            const int k8 = lane & (FAR_ORDER - 1);
+                            x += k8 == 0 ? y1 : k8 == 1 ? y2 : 0.0;
                         }
 #pragma unroll
                         for (int c = MOM_COPIES / 2; c >= 1; c >>= 1) x += __shfl_down(x, c * FAR_ORDER);
