@@ -1,12 +1,15 @@
-O=gpurun_out/r02i; mkdir -p $O
-python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-python bench.py > $O/bench_1gpu.json 2> $O/bench_1gpu.err; python -c "
-import json; d=json.load(open('$O/bench_1gpu.json')); print('config4', d['value'], d['ms_per_step'], d['roofline']['frac'])"
-{ for s in 1 2 3 4 6 8 12 16 24 32 48 64 96 128 160 200; do python scripts/kexp.py --step $s --windows 65536 2>&1 | grep -v "^#" | sed "s/^ lib=libbmxscan.so variant=0/default/"; done
-  python scripts/kexp.py --snps 4000000 --step 200 --windows 18500 2>&1 | grep -v "^#" | sed "s/^ lib=libbmxscan.so variant=0/default4M/"
-  python scripts/kexp.py --snps 4000000 --step 64 --windows 57812 2>&1 | grep -v "^#" | sed "s/^ lib=libbmxscan.so variant=0/default4M/"
-  for s in 32 48 64 96; do BMX_DIAG=1 BMX_DENSE_GAP=0 BMX_LIB_NAME=libbmx_diag.so python scripts/kexp.py --step $s --windows 65536 2>&1 | grep -v "^#" | sed "s/^ lib=libbmx_diag.so variant=0/persite/"; done
-  for s in 48 64 96; do BMX_DIAG=1 BMX_DENSE_GAP=100000 BMX_FORCE_J=4 BMX_LIB_NAME=libbmx_diag.so python scripts/kexp.py --step $s --windows 65536 2>&1 | grep -v "^#" | sed "s/^ lib=libbmx_diag.so variant=0/J4/"; done
-} > $O/stride.txt 2>&1
-grep -c "" $O/stride.txt
+O=gpurun_out/r02k; mkdir -p $O
+python bench.py > $O/bench_1gpu.json 2> $O/bench_1gpu.err
+python bench.py --config 3 --no-cpu-baseline > $O/bench_c3.json 2>/dev/null
+python bench.py --config 5 > $O/bench_c5.json 2>/dev/null
+python bench.py --config 3 --n-spread 10 --no-cpu-baseline > $O/bench_c3_11.json 2>/dev/null
+python bench.py --config 3 --n-spread 40 --no-cpu-baseline > $O/bench_c3_41.json 2>/dev/null
+python scripts/e2e_timing.py > $O/e2e.txt 2>&1
+python scripts/config4_cli_pipeline.py > $O/cfg4_pipeline.txt 2>&1
+python - <<'PY'
+import json
+for f in ('bench_1gpu','bench_c3','bench_c5','bench_c3_11','bench_c3_41'):
+    d=json.load(open('gpurun_out/r02k/'+f+'.json')); r=d['roofline']
+    print(f, round(d['value']), round(d['ms_per_step'],1), round(r['kernel_ms'],1), round(r['frac'],4), round(r.get('fp64_flops_frac',0),4), r.get('traffic'))
+PY
+grep "CLI end\|host buffers\|stages" $O/e2e.txt; tail -2 $O/cfg4_pipeline.txt
