@@ -8,7 +8,7 @@
 //       surface_kernel           <- the full T[A,x,alpha] surface of one site (v1:449-450 wish)
 //
 // The shipped library reads ONE environment variable, BMX_TRACE (stage messages on stderr, no effect on results).
-// Tuning knobs for A/B runs (BMX_LDS_PAD, BMX_DENSE_GAP, BMX_FORCE_J, BMX_FAR_EPS, BMX_MOM_SLOTS, BMX_SPB) exist only
+// Tuning knobs for A/B runs (BMX_LDS_PAD, BMX_DENSE_GAP, BMX_FORCE_J, BMX_FAR_EPS, BMX_MOM_SLOTS, BMX_SPB, BMX_ROWMAX_GLOBAL) exist only
 // in the diagnostic builds (-DBMX_DIAG: `make diag|prof|count`); the scan variant is chosen with bmx_ctx_set_variant().
 //
 // K2 formulation.  For a test site t and linkage value A the reference sums, over the sites
@@ -1873,9 +1873,21 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
         // the kernel reads max |R| and the slot of a row with one load: the slot sits in the low mantissa
         // byte of the (rounded up) maximum; +inf becomes NaN, which never compares as far
         std::vector<double> packed(c->h_rowmax.size());
+        // BMX_ROWMAX_GLOBAL (diagnostic builds): one far threshold per row for all slices (its max |R| over the whole grid) -- what a
+        // classification shared by the slices would have to use; measures how many more near sites that costs
+        std::vector<double> rm_src(c->h_rowmax);
+        if (diag_env("BMX_ROWMAX_GLOBAL")) {
+            const size_t R_ = (size_t)c->rows, S_ = rm_src.size() / R_;
+            for (size_t r = 0; r < R_; r++) {
+                double m = 0.0;
+                bool nan = false;
+                for (size_t sl = 0; sl < S_; sl++) { const double v = rm_src[sl * R_ + r]; if (v != v) nan = true; else m = std::max(m, v); }
+                for (size_t sl = 0; sl < S_; sl++) if (!nan) rm_src[sl * R_ + r] = m;
+            }
+        }
         for (size_t k = 0; k < packed.size(); k++) {
             uint64_t bits;
-            memcpy(&bits, &c->h_rowmax[k], sizeof bits);
+            memcpy(&bits, &rm_src[k], sizeof bits);
             bits = ((bits & ~0xffull) + 0x100ull) | slot[k % (size_t)c->rows];
             memcpy(&packed[k], &bits, sizeof bits);
         }
