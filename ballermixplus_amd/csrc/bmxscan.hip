@@ -20,9 +20,9 @@
 // every few sites so it cannot over/underflow, and takes a single log per (t, A, pair).
 // Lanes run over the (x, alpha_beta) pairs, so nothing is reduced across lanes until the
 // final argmax; alpha_i and row_i are computed lanes-over-sites and broadcast.
-// Far from the test sites (alpha*|R| <= 0.03: three quarters of a window) not even that: the sites'
-// alpha^k are added to per-row moments and the product picks up exp(sum_k +-F^k/k sum_rows R^k M_k)
-// once per zone -- the log1p series to 8th order, cut below 2e-15 (see clr_scan_grouped_kernel).
+// Far from the test sites (alpha*|R| <= 0.05: three quarters of a window) not even that: the sites'
+// alpha^k are added to per-row moments and the product picks up exp(sum_k +-w_k F^k sum_rows R^k M_k)
+// once per zone -- the log1p series to 8th order with economised coefficients (see clr_scan_grouped_kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -535,16 +535,20 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_kernel(ScanParams P) {
 // The argmax is tracked per lane on (binary exponent, mantissa) of the product -- an exact
 // ordering that needs no logarithm; one log per test site is taken at the very end.
 //
-// Inner-loop forms (template parameter MODE_; 2 is what ships, 0 and 1 stay for A/B runs):
+//  * dense test sets (every SNP a test site): the sites between the test sites are the J test sites themselves and
+//    alpha_ij = exp(-A|t_i - t_j|) separates as well (G_i H_j), so that triangle runs in the pair form below.
+//
+// Inner-loop forms (template parameter MODE_; 3 is what ships, 0..2 stay for A/B runs):
 //   0: (E_i, row_i) and alpha_ij reach the lanes by v_readlane, one site per step.
 //   1: they are staged in a wave-private LDS scratch and read back with uniform-address
 //      (broadcast) ds_read, and bulk sites are taken two at a time:
 //          (1 + F v1)(1 + F v2) = 1 + F*(s + F*q),   s = v1 + v2,  q = v1*v2
 //      i.e. 2 FMA + 1 MUL per test site per PAIR of sites (s, q shared by all J test sites).
-//   2: as 1, and passes whose every alpha is <= 1/2 take FOUR sites per step (see the bulk loop).
+//   2: as 1, and list entries with alpha <= 1/2 go FOUR sites per step (see the bulk loop).
+//   3: as 2, and sites with alpha*max|R| <= far_eps are not multiplied at all: their alpha^k go to per-row moments.
 // Measured on gfx950 (profiles/): every VALU instruction of this kernel -- FP64 or not -- costs
-// ~4.5 SIMD cycles at 2 waves/SIMD and ~10 at one, so the design minimises instruction count:
-// 1.98 VALU instructions per 64 evaluations in form 2 at J = 16, vs ~6 in the per-site kernel.
+// ~5-6 SIMD cycles at 2 waves/SIMD and ~10 at one, so the design minimises instruction count:
+// 0.81 VALU instructions per 64 evaluations in form 3 at J = 16 (1.98 in form 2), vs ~6 in the per-site kernel.
 // -DBMX_PROFILE: s_memtime stamps between the sections of the grouped kernel (diagnostic builds only; the
 // stamps serialise outstanding LDS/scalar loads, so the split is approximate).  Sections: 0 sites between
 // the test sites, 1 zone set-up, 2 per-pass work, 3 products over the near list, 4 ragged-end masks,
