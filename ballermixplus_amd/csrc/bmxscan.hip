@@ -32,6 +32,7 @@
 #include <errno.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <unordered_set>
@@ -239,6 +240,13 @@ __global__ void locate_kernel(const double *genpos, int64_t N, const double *tes
     center_hi[t] = a;  // first index with genpos > test position (sites in between are ties)
 }
 
+// index gaps between neighbouring test sites at a strided sample of all of them (set_tests: test-site density)
+__global__ void gap_kernel(const int64_t *center, int64_t stride, int64_t ns, int64_t *gap) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    gap[k] = center[k * stride + 1] - center[k * stride];
+}
+
 // LUT row of a site: 2 bytes per site normally (<= 65535 rows), 4 when the table is larger
 // (hundreds of distinct sample sizes).
 struct RowArray {
@@ -421,7 +429,8 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_kernel(ScanParams P) {
         const int hi = (int)min(P.win_hi[t], (int64_t)N - 1);
         const int c = (int)P.center[t];
         double bestM = 1.0;
-        int bestK = (131072 << 13) | 8191;          // (clamped exponent + 2^17) << 13 | iA; iA = 8191: none yet
+        int bestEc = 131072, bestA = -1;            // clamped exponent + 2^17 of the best product so far, and its A index (-1: none yet);
+                                                    // not packed into one word as in the grouped kernel: this kernel takes any nA
 
         for (int iA = 0; iA < P.nA; ++iA) {
             const double Aval = P.A[iA];
@@ -492,17 +501,16 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_kernel(ScanParams P) {
             }
             renorm(acc, E);
             const int ec = min(max(E, -131071), 131071) + 131072;
-            const int eb = bestK >> 13;
-            if (((ec > eb) || (ec == eb && acc > bestM)) && p < P.npairs) {       // strict '>' (v1:501); iA ascending
+            if (((ec > bestEc) || (ec == bestEc && acc > bestM)) && p < P.npairs) {       // strict '>' (v1:501); iA ascending
                 bestM = acc;
-                bestK = (ec << 13) | iA;
+                bestEc = ec;
+                bestA = iA;
             }
         }
         // wave argmax on (exponent, mantissa), ties to the smaller linear index = the reference's first strict
         // maximum in (A, x, alpha_beta) loop order; the logarithm is finalize_kernel's
-        const int biA = bestK & 8191;
-        int bE = bestK >> 13;
-        int bL = biA == 8191 ? 0x7fffffff : biA * P.npairs + p;
+        int bE = bestEc;
+        int bL = bestA < 0 ? 0x7fffffff : bestA * P.npairs + p;
         for (int off = 32; off > 0; off >>= 1) {
             const int oE = __shfl_xor(bE, off);
             const double oM = __shfl_xor(bestM, off);
@@ -1320,6 +1328,838 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 #endif
 }
 
+// ----------------------------------------------------------------------------- K2, prepared (round 3)
+// Everything the grouped kernel did per pass of 64 sites -- loading positions and rows, exp(-A d), the near / far
+// classification, the ds_add_f64 moment sums, the ragged-end counts -- is the same for all eight 64-pair slices of a group of
+// test sites, and the grouped kernel did it once per slice (a quarter of its cycles, round-2 profiles).  Here it is done ONCE
+// per group, by a separate lanes-over-sites kernel with a small register footprint (prep_kernel), which writes what the
+// pair-parallel kernel needs as one sequential stream per group ("blob") in HBM; clr_scan_prepared_kernel -- one wave per
+// (group, slice) as before -- then only multiplies, folds and flushes, reading its blob through a ring in LDS.
+//
+//   blob(group)  = for iA in 0..nA-1: zone(iA, right), zone(iA, left);   16-byte units, padded to a multiple of 4
+//   zone         = header (3 units): {magic | rag, n_pair, n_quad, n_occ} {n_far, n_rag, end index | ZONE_DONE, tag} {n_j bytes}
+//                  near list: n_pair entries with alpha > 1/2 (padded to whole blocks), then n_quad entries (multiple of 4),
+//                             each (E_i f64, row offset i32), in walk order; 8 neutral guard entries (what the block loops
+//                             request one block ahead)
+//                  moments:   n_occ entries of 5 units: (M_1, row offset) (M_2, M_3) (M_4, M_5) (M_6, M_7) (M_8, -)
+//                  ragged end (rag only): n_rag entries (E, row offset) + 1 guard
+// Sizes come from a counting pass of the same code (prep_kernel<J, false>: identical predicates, no exp, no stores) run when
+// the test sites are set, then an exclusive scan; the fill pass (prep_kernel<J, true>) and the consumer run per launch range.
+// The far test is slice-independent now: alpha * max_grid |R[row]| <= far_eps, evaluated in the exponent domain
+// (A d >= log(max|R| / far_eps), rounded up), so both passes classify from A d alone.
+constexpr int PREP_HDR = 3, PREP_GUARD = 8, PREP_MOM = 5, PREP_RAG_GUARD = 1;
+constexpr int PREP_MAGIC = 0x5a0e0000;
+constexpr int RING_UNITS = 256, RING_MIRROR = 16, AUX_UNITS = 32;     // per wave: ring of 4 x 64 units + 16 mirrored + scratch
+constexpr int PREP_ZONE_DONE = -0x7fffffff;
+constexpr int PREP_THREADS = 256;
+constexpr int PREP_THR_LDS_MAX = 4096;                                // rows whose far thresholds are staged in LDS
+
+struct PrepParams {
+    const double *genpos;
+    RowArray row;
+    int64_t N;
+    int rows, rowmul;             // consumer's row offset = row * rowmul (64: LDS slice, NP: global table)
+    const double *A;
+    int nA;
+    const double *test_gen;       // the slot's test sites (absolute indexing: group g = test sites [g J, g J + J))
+    const int64_t *win_lo, *win_hi, *center, *center_hi;
+    int64_t M;
+    double zcut;
+    const double *rowthr;         // [rows]: A d from which a site of the row is far, the row's moment slot in the low byte
+    int thr_in_lds;
+    const uint8_t *kmom;
+    const int *row_of_slot;       // [MOM_SLOTS]
+    int mom_slots;
+    int64_t g_begin, g_end;       // groups of this launch
+    int32_t *blob_units;          // counting pass: [groups of the slot]
+    const int64_t *blob_prefix;   // fill pass: exclusive prefix of blob_units
+    int64_t prefix_base;          // ... of the launch range's first group: the arena holds the range's blobs from unit 0
+    ScratchEnt *arena;
+    int *status;                  // bit 0: a blob came out longer/shorter than counted, bit 1: bad header seen by the consumer
+};
+
+template <int J, bool FILL>
+__global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds_p[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x / WAVE;
+    const int N = (int)P.N;
+    const int thr_len = P.thr_in_lds ? ((P.rows + 1) & ~1) : 0;
+    if (P.thr_in_lds) {
+        for (int idx = threadIdx.x; idx < P.rows; idx += blockDim.x) lds_p[idx] = P.rowthr[idx];
+        __syncthreads();
+    }
+    const int mom_len = (P.mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER;
+    double *mom = lds_p + thr_len + wave * (mom_len + WAVE);
+    double *ragscr = mom + mom_len;
+    for (int idx = lane; idx < mom_len; idx += WAVE) mom[idx] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t grp = P.g_begin + (int64_t)blockIdx.x * nw + wave;
+    if (grp >= P.g_end) return;                     // (no workgroup barrier below this line)
+    auto thr_of = [&](int r) -> double {
+        double v;
+        if (P.thr_in_lds) v = lds_p[r]; else v = P.rowthr[r];
+        return v;
+    };
+    auto rank = [&](unsigned long long m) {
+        return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    };
+    constexpr int BS = J >= 16 ? 4 : 8;             // sites per pair block of the consumer
+
+    // group prologue: the consumer's, value for value
+    const int64_t tb = grp * J;
+    const int nvalid = (int)min((int64_t)J, P.M - tb);
+    const int jl = lane % J;
+    const int jj = min(jl, nvalid - 1);
+    const double tj = P.test_gen[tb + jj];
+    int lo_j = (int)max(P.win_lo[tb + jj], (int64_t)0);
+    int hi_j = (int)min(P.win_hi[tb + jj], (int64_t)N - 1);
+    if (jl >= nvalid) { lo_j = 1; hi_j = 0; }
+    const double t0 = readlane_f64(tj, 0), tL = readlane_f64(tj, J - 1);
+    const int c0 = (int)P.center[tb], cU = (int)P.center_hi[tb + nvalid - 1];
+    int lo_max = 0, hi_min = N - 1;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int a = __builtin_amdgcn_readlane(lo_j, j), b = __builtin_amdgcn_readlane(hi_j, j);
+        if (j < nvalid) { lo_max = max(lo_max, a); hi_min = min(hi_min, b); }
+    }
+    int L_int = min(c0, hi_min + 1), R_int = max(cU, lo_max);
+    if (hi_min < lo_max) { L_int = c0; R_int = c0; hi_min = -1; lo_max = N; }   // no bulk zone
+
+    int wpos = 0;                                   // units of the blob written (counted) so far
+    ScratchEnt *out = nullptr;
+    if (FILL) out = P.arena + (P.blob_prefix[grp] - P.prefix_base);
+
+    for (int iA = 0; iA < P.nA; ++iA) {
+        const double A = P.A[iA];
+        const int kmom = min((int)P.kmom[iA], P.mom_slots);
+        auto zone = [&](int base, int dir, double tnear, double tfar, int tag) {
+            const int zbase = wpos, nbase = zbase + PREP_HDR;
+            int n_pair = 0, n_pair_pad = 0, n_quad = 0, nfar_tot = 0, pad_ro = 0;
+            bool pair_open = true, seen = false;
+            double m1p = 0.0, m2p = 0.0;
+            auto close_pairs = [&]() {
+                n_pair_pad = (n_pair + BS - 1) & ~(BS - 1);
+                if (FILL && lane < n_pair_pad - n_pair) out[nbase + n_pair + lane] = ScratchEnt{0.0, pad_ro, 0};
+                pair_open = false;
+            };
+            int i = base + dir * lane;
+            double g_nx = P.genpos[min(max(i, 0), N - 1)];
+            int r_nx = (int)P.row[min(max(i, 0), N - 1)];
+            while (true) {
+                const bool ok = dir > 0 ? (i <= hi_min) : (i >= lo_max);
+                const double g = g_nx;
+                const int rraw = r_nx;
+                const int inx = i + dir * WAVE;
+                g_nx = P.genpos[min(max(inx, 0), N - 1)];
+                r_nx = (int)P.row[min(max(inx, 0), N - 1)];
+                const bool bulk = ok && (A * fabs(g - tfar) <= P.zcut);
+                const int cnt = __popcll(__ballot(bulk));
+                if (cnt) {
+                    const double zn = A * fabs(g - tnear);
+                    const double th = thr_of(rraw);
+                    const int slot = __double2loint(th) & 0xff;
+                    const bool moml = bulk && slot < kmom && zn >= th && nfar_tot < FAR_CAP;
+                    const bool nearl = bulk && !moml;
+                    const bool pairl = nearl && zn < LN2;
+                    const unsigned long long mm = __ballot(moml), mp = __ballot(pairl), mq = __ballot(nearl && !pairl);
+                    const int nfar = __popcll(mm);
+                    if (!seen) { pad_ro = __builtin_amdgcn_readlane(rraw, 0) * P.rowmul; seen = true; }   // lane 0: a site of the zone
+                    double Ev = 0.0;
+                    if (FILL) Ev = bulk ? exp_neg(zn) : 0.0;
+                    if (nfar) {
+                        if (moml) {
+                            double *mr = mom + (slot ? slot + MOM_COPIES - 1 : (lane & (MOM_COPIES - 1))) * FAR_ORDER;
+                            if (FILL) {
+                                // a lane adds only the powers whose term can exceed 2e-15: x = alpha max|R| = far_eps exp(-(z - th))
+                                const double d = zn - th;
+                                const double E2 = Ev * Ev;
+                                if (slot == 0) { m1p += Ev; m2p += E2; }
+                                else { atomicAdd(mr, Ev); atomicAdd(mr + 1, E2); }
+                                if (d < 7.94) {
+                                    const double E3 = E2 * Ev;
+                                    atomicAdd(mr + 2, E3);
+                                    if (d < 5.13) {
+                                        const double E4 = E2 * E2;
+                                        atomicAdd(mr + 3, E4);
+                                        if (d < 3.46) {
+                                            atomicAdd(mr + 4, E4 * Ev);
+                                            if (d < 2.36) {
+                                                atomicAdd(mr + 5, E4 * E2);
+                                                if (d < 1.58) {
+                                                    atomicAdd(mr + 6, E4 * E3);
+                                                    if (d < 0.99) atomicAdd(mr + 7, E4 * E4);
+                                                }
+                                            }
+                                        }
+                                    }
+                                }
+                            } else {
+                                mom[(slot ? slot + MOM_COPIES - 1 : 0) * FAR_ORDER] = 1.0;      // occupancy only
+                            }
+                        }
+                        nfar_tot += nfar;
+                    }
+                    if (pair_open) {
+                        if (FILL && pairl) out[nbase + n_pair + rank(mp)] = ScratchEnt{Ev, rraw * P.rowmul, 0};
+                        n_pair += __popcll(mp);
+                        if (__ballot(bulk && !(zn < LN2)) != 0ull || cnt < WAVE) close_pairs();
+                    }
+                    if (!pair_open) {
+                        if (FILL && nearl && !pairl) out[nbase + n_pair_pad + n_quad + rank(mq)] = ScratchEnt{Ev, rraw * P.rowmul, 0};
+                        n_quad += __popcll(mq);
+                    }
+                }
+                base += dir * cnt;
+                if (cnt < WAVE) break;
+                i = inx;
+            }
+            if (pair_open) close_pairs();
+            const int n_quad_pad = (n_quad + 3) & ~3;
+            if (FILL) {
+                if (lane < n_quad_pad - n_quad) out[nbase + n_pair_pad + n_quad + lane] = ScratchEnt{0.0, pad_ro, 0};
+                if (lane < PREP_GUARD) out[nbase + n_pair_pad + n_quad_pad + lane] = ScratchEnt{0.0, pad_ro, 0};
+            }
+            wpos = nbase + n_pair_pad + n_quad_pad + PREP_GUARD;
+
+            // ragged far end (see the grouped kernel): per-window counts n_j by bisection with the scan's own predicate
+            int nrag_v = 0, nrmax = 0;
+            bool rag = false;
+            double zr = 0.0;
+            int rr = 0;
+            if (kmom) {
+                const int ir = base + dir * lane;
+                const bool inr = ir >= 0 && ir < N;
+                const int ic = min(max(ir, 0), N - 1);
+                const double g = P.genpos[ic];
+                rr = (int)P.row[ic];
+                bool okr = __ballot(inr && (dir > 0 ? g <= tnear : g >= tnear)) == 0ull &&
+                           __ballot(dir > 0 ? lo_j > base : hi_j < base) == 0ull;
+                if (okr) {
+                    ragscr[lane] = g;
+                    __builtin_amdgcn_wave_barrier();
+                    const int cnt1 = min(max(dir > 0 ? hi_j - base + 1 : base - lo_j + 1, 0), WAVE);
+                    int lo_n = 0, hi_n = WAVE;
+#pragma unroll
+                    for (int it = 0; it < 7; ++it) {
+                        const int mid = min((lo_n + hi_n) >> 1, WAVE - 1);
+                        const bool pm = A * fabs(ragscr[mid] - tj) <= P.zcut;
+                        const bool act = lo_n < hi_n;
+                        lo_n = act && pm ? mid + 1 : lo_n;
+                        hi_n = act && !pm ? mid : hi_n;
+                    }
+                    nrag_v = min(cnt1, lo_n);
+                    __builtin_amdgcn_wave_barrier();
+                    const int nb = dir > 0 ? __shfl_up(nrag_v, 1) : __shfl_down(nrag_v, 1);
+                    const bool edge = dir > 0 ? jl == 0 : jl == J - 1;
+                    okr = __ballot(!edge && nb > nrag_v) == 0ull;
+                    nrmax = __builtin_amdgcn_readlane(nrag_v, dir > 0 ? J - 1 : 0);
+                }
+                if (okr && nrmax > 0 && nrmax < WAVE) {
+                    zr = A * fabs(g - tnear);
+                    const bool far3 = lane >= nrmax || zr >= thr_of(rr) + 5.13;      // alpha max|R| <= 3e-4; NaN (absent row): false
+                    rag = __ballot(far3) == ~0ull;
+                }
+            }
+
+            // moments of the occupied slots, slot order
+            int n_occ = 0;
+            if (nfar_tot) {
+                __builtin_amdgcn_wave_barrier();
+                {   // slot 0: MOM_COPIES copies read lane-parallel (copy = lane / order, moment = lane % order) + the private sums
+                    double x = 0.0;
+                    if (lane < MOM_COPIES * FAR_ORDER) {
+                        x = mom[lane];
+                        mom[lane] = 0.0;
+                    }
+                    if (FILL) {
+                        double y1 = m1p, y2 = m2p;
+#pragma unroll
+                        for (int off = 1; off < FAR_ORDER; off <<= 1) {
+                            y1 += __shfl_xor(y1, off);
+                            y2 += __shfl_xor(y2, off);
+                        }
+                        const int k8 = lane & (FAR_ORDER - 1);
+                        x += k8 == 0 ? y1 : k8 == 1 ? y2 : 0.0;
+                    }
+#pragma unroll
+                    for (int c = MOM_COPIES / 2; c >= 1; c >>= 1) x += __shfl_down(x, c * FAR_ORDER);
+                    const double m0 = readlane_f64(x, 0);
+                    if (m0 != 0.0) {
+                        if (FILL) {
+                            double m[FAR_ORDER];
+#pragma unroll
+                            for (int k = 0; k < FAR_ORDER; ++k) m[k] = readlane_f64(x, k);
+                            if (lane == 0) {
+                                ScratchEnt *o = out + wpos;
+                                o[0] = ScratchEnt{m[0], P.row_of_slot[0] * P.rowmul, 0};
+                                double2 *o2 = reinterpret_cast<double2 *>(o + 1);
+                                o2[0] = double2{m[1], m[2]};
+                                o2[1] = double2{m[3], m[4]};
+                                o2[2] = double2{m[5], m[6]};
+                                o2[3] = double2{m[7], 0.0};
+                            }
+                        }
+                        n_occ = 1;
+                    }
+                }
+                for (int s0 = 1; s0 < kmom; s0 += WAVE) {
+                    const int s = s0 + lane;
+                    double m[FAR_ORDER];
+#pragma unroll
+                    for (int k = 0; k < FAR_ORDER; ++k) m[k] = 0.0;
+                    if (s < kmom) {
+                        double *ms = mom + (s + MOM_COPIES - 1) * FAR_ORDER;
+#pragma unroll
+                        for (int k = 0; k < FAR_ORDER; ++k) { m[k] = ms[k]; ms[k] = 0.0; }
+                    }
+                    const bool occ = m[0] != 0.0;
+                    const unsigned long long mo = __ballot(occ);
+                    if (FILL && occ) {
+                        ScratchEnt *o = out + wpos + PREP_MOM * (n_occ + rank(mo));
+                        o[0] = ScratchEnt{m[0], P.row_of_slot[s] * P.rowmul, 0};
+                        double2 *o2 = reinterpret_cast<double2 *>(o + 1);
+                        o2[0] = double2{m[1], m[2]};
+                        o2[1] = double2{m[3], m[4]};
+                        o2[2] = double2{m[5], m[6]};
+                        o2[3] = double2{m[7], 0.0};
+                    }
+                    n_occ += __popcll(mo);
+                }
+                __builtin_amdgcn_wave_barrier();
+                wpos += PREP_MOM * n_occ;
+            }
+            if (rag) {
+                if (FILL) {
+                    if (lane < nrmax) out[wpos + lane] = ScratchEnt{exp_neg(zr), rr * P.rowmul, 0};
+                    if (lane == nrmax) out[wpos + lane] = ScratchEnt{0.0, rr * P.rowmul, 0};
+                }
+                wpos += nrmax + PREP_RAG_GUARD;
+            }
+            if (FILL) {
+                // n_j of the J test sites as bytes (n_j < 64)
+                int w = nrag_v & 0xff;
+                w |= (__shfl_down(nrag_v, 1) & 0xff) << 8;
+                w |= (__shfl_down(nrag_v, 2) & 0xff) << 16;
+                w |= (__shfl_down(nrag_v, 3) & 0xff) << 24;
+                const int w0 = __builtin_amdgcn_readlane(w, 0), w1 = __builtin_amdgcn_readlane(w, 4 % J),
+                          w2 = __builtin_amdgcn_readlane(w, 8 % J), w3 = __builtin_amdgcn_readlane(w, 12 % J);
+                if (lane == 0) {
+                    int4 *o = reinterpret_cast<int4 *>(out + zbase);
+                    o[0] = int4{PREP_MAGIC | (rag ? 1 : 0), n_pair_pad, n_quad_pad, n_occ};
+                    o[1] = int4{nfar_tot, rag ? nrmax : 0, rag ? PREP_ZONE_DONE : base, tag};
+                    o[2] = int4{w0, w1, w2, w3};
+                }
+            }
+        };
+        zone(R_int, +1, tL, t0, iA * 2);
+        zone(L_int - 1, -1, t0, tL, iA * 2 + 1);
+    }
+    const int units = (wpos + 3) & ~3;
+    if (!FILL) {
+        if (lane == 0) P.blob_units[grp] = units;
+    } else {
+        if (lane == 0 && (int64_t)units != P.blob_prefix[grp + 1] - P.blob_prefix[grp]) atomicOr(P.status, 1);
+    }
+}
+
+// exclusive prefix sums of the blob sizes (one workgroup; the array has one entry per group of test sites)
+__global__ __launch_bounds__(1024) void prefix_kernel(const int32_t *u, int64_t n, int64_t *pre) {
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b = min((int64_t)t * per, n), e = min(b + per, n);
+    int64_t s = 0;
+    for (int64_t i = b; i < e; ++i) s += u[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int64_t v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int64_t run = part[t] - s;
+    for (int64_t i = b; i < e; ++i) { pre[i] = run; run += u[i]; }
+    if (t == 1023) pre[n] = part[1023];
+}
+
+struct PrepView {
+    const ScratchEnt *arena;
+    const int64_t *blob_prefix;   // the slot's exclusive prefix, indexed by absolute group
+    int64_t prefix_base;          // prefix of the launch range's first group
+    int64_t grp_base;             // absolute index of the launch range's first group
+    int *status;
+};
+
+template <int J, bool USE_LDS>
+__global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(ScanParams P, PrepView V) {
+    extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then per wave: ring + scratch, sites between the test sites
+    constexpr int SP = WAVE / J;
+    constexpr int BS = J >= 16 ? 4 : 8;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int slice = blockIdx.x % P.nslices;
+    const int64_t chunk = blockIdx.x / P.nslices;
+    const int p = slice * WAVE + lane;
+    const int jl = lane % J, sl = lane / J;
+    const int N = (int)P.N;
+    const int nwv = blockDim.x / WAVE;
+
+    if (USE_LDS) {
+        const int total = P.rows * WAVE;
+        for (int idx = threadIdx.x; idx < total; idx += blockDim.x)
+            lds_R[idx] = P.Rt[(size_t)(idx >> 6) * P.NP + slice * WAVE + (idx & 63)];
+    }
+    const char *Rb = reinterpret_cast<const char *>(P.Rt + slice * WAVE);
+    const unsigned lane8 = (unsigned)lane * 8u;
+    const int rowmul = USE_LDS ? WAVE : P.NP;
+    auto loadR = [&](int rowoff) -> double {
+        return USE_LDS ? lds_R[rowoff + lane] : *reinterpret_cast<const double *>(Rb + ((unsigned)rowoff * 8u + lane8));
+    };
+    double *lds_tail = lds_R + (USE_LDS ? P.rows * WAVE : 0);
+    constexpr int WAVE_UNITS = RING_UNITS + RING_MIRROR + AUX_UNITS;
+    ScratchEnt *ring = reinterpret_cast<ScratchEnt *>(lds_tail) + wave * WAVE_UNITS;
+    ScratchEnt *scr = ring + RING_UNITS + RING_MIRROR;              // 32 units of wave-private scratch
+    double *scr_d = reinterpret_cast<double *>(scr);
+    double *mid_base = lds_tail + nwv * WAVE_UNITS * 2;
+    // the ring and the scratch start out as valid neutral entries (row offset 0): whatever is read ahead of the stream is a
+    // legal row reference
+    for (int idx = lane; idx < WAVE_UNITS; idx += WAVE) ring[idx] = ScratchEnt{0.0, 0, 0};
+    if (USE_LDS) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+
+    const int64_t ngroups = (P.M + J - 1) / J;
+    const int64_t gpb = P.sites_per_block / J;
+    const int64_t g_end = min((chunk + 1) * gpb, ngroups);
+    for (int64_t grp = chunk * gpb + wave; grp < g_end; grp += nwv) {
+        const int64_t tb = grp * J;
+        const int nvalid = (int)min((int64_t)J, P.M - tb);
+        int jl_g = jl, lane_g = lane, wave_g = wave;
+        asm volatile("" : "+v"(jl_g), "+v"(lane_g), "+s"(wave_g));
+        double *mid_g = mid_base + wave_g * (MID_CAP + MID_CAP / 2);
+        int *mid_ro = reinterpret_cast<int *>(mid_g + MID_CAP);
+        const int jj = min(jl_g, nvalid - 1);
+        const double tj = P.test_gen[tb + jj];
+        int lo_j = (int)max(P.win_lo[tb + jj], (int64_t)0);
+        int hi_j = (int)min(P.win_hi[tb + jj], (int64_t)N - 1);
+        if (jl >= nvalid) { lo_j = 1; hi_j = 0; }
+        const double t0 = readlane_f64(tj, 0), tL = readlane_f64(tj, J - 1);
+        const int c0 = (int)P.center[tb], cU = (int)P.center_hi[tb + nvalid - 1];
+        int lo_max = 0, hi_min = N - 1;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int a = __builtin_amdgcn_readlane(lo_j, j), b = __builtin_amdgcn_readlane(hi_j, j);
+            if (j < nvalid) { lo_max = max(lo_max, a); hi_min = min(hi_min, b); }
+        }
+        int L_int = min(c0, hi_min + 1), R_int = max(cU, lo_max);
+        if (hi_min < lo_max) { L_int = c0; R_int = c0; hi_min = -1; lo_max = N; }   // no bulk zone
+        const bool staged = R_int - L_int <= MID_CAP;
+        if (staged && lane_g < R_int - L_int) {
+            mid_g[lane_g] = P.genpos[L_int + lane_g];
+            mid_ro[lane_g] = (int)P.row[L_int + lane_g] * rowmul;
+        }
+        __builtin_amdgcn_wave_barrier();
+        bool mid_tri = false;
+        if (BMX_MIDTRI) {
+            const bool same = staged && (R_int - L_int == J) && nvalid == J && lo_max <= L_int && hi_min >= R_int - 1;
+            if (same) {
+                const double gm = mid_g[jl_g];
+                const double tprev = __shfl_up(tj, 1);
+                mid_tri = __ballot(!(gm == tj && (jl_g == 0 || tj > tprev))) == 0ull;
+            }
+        }
+
+        // the group's blob, streamed through the ring: `pos` units consumed, [.., staged_u) in the ring, the next 64 in flight
+        // (the unit in flight is held as two doubles -- bit patterns, never arithmetic -- so that it stays in registers)
+        const double2 *src = reinterpret_cast<const double2 *>(V.arena + (V.blob_prefix[V.grp_base + grp] - V.prefix_base));
+        double2 *ring2 = reinterpret_cast<double2 *>(ring);
+        int pos = 0, staged_u = 0;
+        double nx_a, nx_b;
+        {
+            const double2 t = src[lane];
+            nx_a = t.x; nx_b = t.y;
+        }
+        bool bad = false;
+        auto stage = [&]() {
+            const int slot = (staged_u >> 6) & 3;
+            ring2[slot * WAVE + lane] = double2{nx_a, nx_b};
+            if (slot == 0 && lane < RING_MIRROR) ring2[RING_UNITS + lane] = double2{nx_a, nx_b};   // units 0..15 again behind the ring's
+            staged_u += WAVE;                                                       // end: any 16 consecutive units read without a wrap
+            const double2 t = src[staged_u + lane];
+            nx_a = t.x; nx_b = t.y;
+            __builtin_amdgcn_wave_barrier();
+        };
+        // [pos, pos + 80) is in the ring.  `pos` moves by at most 64 units between two calls (a block, an entry, a guard, a
+        // ragged end of < 64 sites), so one step restores the invariant
+        auto need = [&]() {
+            if (pos + 80 > staged_u) stage();
+        };
+        stage();
+        stage();
+
+        double acc[J], bestM[J];
+        int E[J], bestK[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) { bestM[j] = 1.0; bestK[j] = (131072 << 13) | 8191; }
+
+        for (int iA = 0; iA < P.nA; ++iA) {
+            const double A = P.A[iA];
+            int bits = 0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) { acc[j] = 1.0; E[j] = 0; }
+            auto renorm_all = [&]() {
+#pragma unroll
+                for (int j = 0; j < J; ++j) renorm(acc[j], E[j]);
+                bits = 0;
+            };
+            auto spend = [&](int nbits) {
+                if (bits + nbits > 1000) renorm_all();
+                bits += nbits;
+            };
+            const int span_generic = max(P.span_hi, 54);
+
+            auto apply_pass = [&](double alpha, int rowoff, unsigned long long m_in, double *buf) {
+                buf[lane] = alpha;
+                __builtin_amdgcn_wave_barrier();
+                double Rpre[SP];
+                if (!USE_LDS) {
+#pragma unroll
+                    for (int s = 0; s < SP; ++s) Rpre[s] = loadR(__builtin_amdgcn_readlane(rowoff, s * J));
+                }
+#pragma unroll
+                for (int s = 0; s < SP; ++s) {
+                    if (((m_in >> (s * J)) & ((1ull << J) - 1ull)) == 0ull) continue;
+                    const double R = USE_LDS ? loadR(__builtin_amdgcn_readlane(rowoff, s * J)) : Rpre[s];
+                    const double2 *a2 = reinterpret_cast<const double2 *>(buf + s * J);
+#pragma unroll
+                    for (int j = 0; j < J; j += 2) {
+                        const double2 a = a2[j >> 1];
+                        acc[j] *= fma(a.x, R, 1.0);
+                        acc[j + 1] *= fma(a.y, R, 1.0);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+            auto generic_core = [&](int i, bool inr, double g, int rowoff, int dir) -> bool {
+                const bool inwin = inr && i >= lo_j && i <= hi_j;
+                const double z = A * fabs(g - tj);
+                const bool in = inwin && (z <= P.zcut) && (g != tj);
+                const bool fin = lo_j > hi_j ||
+                                 (dir > 0 ? (!inr || i > hi_j || (i >= lo_j && g > tj && z > P.zcut))
+                                          : (!inr || i < lo_j || (i <= hi_j && g < tj && z > P.zcut)));
+                const unsigned long long m_in = __ballot(in);
+                if (m_in != 0ull) {
+                    const double alpha = in ? exp_neg(z) : 0.0;
+                    spend(SP * (__ballot(in && z < 0.6931471805599453) == 0ull ? max(P.span_hi, 2) : span_generic));
+                    apply_pass(alpha, rowoff, m_in, scr_d);
+                }
+                return __ballot(fin) == ~0ull;
+            };
+            auto generic_pass = [&](int b, int dir, int lim, bool from_lds) -> bool {
+                const int i = b + dir * sl;
+                const bool inr = dir > 0 ? (i < lim) : (i > lim);
+                double g = 0.0;
+                int rowoff = 0;
+                if (from_lds) {
+                    if (inr) { g = mid_g[i - L_int]; rowoff = mid_ro[i - L_int]; }
+                } else {
+                    if (inr) { g = P.genpos[i]; rowoff = (int)P.row[i] * rowmul; }
+                }
+                return generic_core(i, inr, g, rowoff, dir);
+            };
+
+            // one zone of the blob: near-list products, fold of the moments, flush; returns where the generic walk goes on
+            auto bulk_zone = [&](int dir, double tnear) -> int {
+                if (bad) return PREP_ZONE_DONE;
+                double F[J];
+                {
+                    const double fv = exp_neg(A * fabs(tnear - tj));
+#pragma unroll
+                    for (int j = 0; j < J; ++j) F[j] = readlane_f64(fv, j);
+                }
+                need();
+                const int4 *hp = reinterpret_cast<const int4 *>(ring + (pos & (RING_UNITS - 1)));
+                const int4 h0 = hp[0], h1 = hp[1];
+                const int magic = __builtin_amdgcn_readfirstlane(h0.x);
+                const int n_pair = __builtin_amdgcn_readfirstlane(h0.y), n_quad = __builtin_amdgcn_readfirstlane(h0.z);
+                const int n_occ = __builtin_amdgcn_readfirstlane(h0.w);
+                const int nfar_tot = __builtin_amdgcn_readfirstlane(h1.x), nrmax = __builtin_amdgcn_readfirstlane(h1.y);
+                const int base_end = __builtin_amdgcn_readfirstlane(h1.z);
+                const bool rag = (magic & 1) != 0;
+                if ((magic & ~1) != PREP_MAGIC || n_pair < 0 || n_quad < 0 || n_pair > N + 8 || n_quad > N + 8 || n_occ < 0 || n_occ > MOM_SLOTS ||
+                    nrmax < 0 || nrmax >= WAVE) {
+                    bad = true;
+                    return PREP_ZONE_DONE;
+                }
+                // n_j of this lane's test site (ragged end)
+                const int nrag_v = (int)reinterpret_cast<const unsigned char *>(hp + 2)[jl];
+                pos += PREP_HDR;
+
+                if (n_pair > 0) {
+                    need();
+                    const double e0 = ring[pos & (RING_UNITS - 1)].e;       // the nearest site: the largest alpha of the list
+                    const double om = 1.0 - e0, op = fma(e0, P.rmax, 1.0);
+                    const int pend_lo = 1024 - ((__builtin_amdgcn_readfirstlane(__double2hiint(om)) >> 20) & 0x7ff);
+                    const int pend_hi = ((__builtin_amdgcn_readfirstlane(__double2hiint(op)) >> 20) & 0x7ff) - 1022;
+                    const int span8 = 8 * min(max(pend_hi, pend_lo), 125);
+                    double Rp[BS], ep[BS];
+                    if (BMX_PAIR_PREFETCH) {
+                        const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
+#pragma unroll
+                        for (int u = 0; u < BS; ++u) {
+                            const ScratchEnt en = rp[u];
+                            ep[u] = en.e;
+                            Rp[u] = loadR(en.ro);
+                        }
+                    }
+                    for (int l0 = 0; l0 < n_pair; l0 += BS) {
+                        need();
+                        const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
+                        spend(span8 * BS / 8);
+                        double v[BS];
+                        if (BMX_PAIR_PREFETCH) {
+#pragma unroll
+                            for (int u = 0; u < BS; ++u) v[u] = ep[u] * Rp[u];
+#pragma unroll
+                            for (int u = 0; u < BS; ++u) {
+                                const ScratchEnt en = rp[BS + u];
+                                ep[u] = en.e;
+                                Rp[u] = loadR(en.ro);
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < BS; ++u) {
+                                const ScratchEnt en = rp[u];
+                                v[u] = en.e * loadR(en.ro);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < BS; u += 2) {
+                            const double sv = v[u] + v[u + 1], qv = v[u] * v[u + 1];
+#pragma unroll
+                            for (int j = 0; j < J; ++j) acc[j] *= fma(F[j], fma(F[j], qv, sv), 1.0);
+                        }
+                        pos += BS;
+                    }
+                }
+                if (n_quad > 0) {
+                    need();
+                    int span8q = 0;
+                    double Rn[4], en_e[4];
+                    {
+                        const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const ScratchEnt en = rp[u];
+                            en_e[u] = en.e;
+                            Rn[u] = loadR(en.ro);
+                        }
+                    }
+                    for (int l0 = 0; l0 < n_quad; l0 += 4) {
+                        need();
+                        const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
+                        if ((l0 & 63) == 0) {
+                            // every factor of the next 64 entries lies in [1/2, 1 + e0 Rmax], e0 the first (largest) alpha among them
+                            const double op = fma(rp[0].e, P.rmax, 1.0);
+                            const int hi = ((__builtin_amdgcn_readfirstlane(__double2hiint(op)) >> 20) & 0x7ff) - 1022;
+                            span8q = 8 * min(max(hi, 2), 125);
+                        }
+                        spend(span8q / 2);
+                        double v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = en_e[u] * Rn[u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const ScratchEnt en = rp[4 + u];
+                            en_e[u] = en.e;
+                            Rn[u] = loadR(en.ro);
+                        }
+                        const double s01 = v[0] + v[1], q01 = v[0] * v[1];
+                        const double s23 = v[2] + v[3], q23 = v[2] * v[3];
+                        const double e1 = s01 + s23;
+                        const double e2 = fma(s01, s23, q01 + q23);
+                        const double e3 = fma(q01, s23, q23 * s01);
+                        const double e4 = q01 * q23;
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            double t = fma(F[j], e4, e3);
+                            t = fma(F[j], t, e2);
+                            t = fma(F[j], t, e1);
+                            acc[j] *= fma(F[j], t, 1.0);
+                            if ((j & (BMX_QSB - 1)) == BMX_QSB - 1) __builtin_amdgcn_sched_barrier(0);
+                        }
+                        pos += 4;
+                    }
+                }
+                pos += PREP_GUARD;
+
+                if (nfar_tot || rag) {
+                    double pk[FAR_ORDER];
+#pragma unroll
+                    for (int k = 0; k < FAR_ORDER; ++k) pk[k] = 0.0;
+                    auto fold = [&](const double m1, const double2 ma, const double2 mb, const double2 mc, const double2 md, const double R) {
+                        const double R2 = R * R, R3 = R2 * R, R4 = R2 * R2;
+                        pk[0] = fma(m1, R, pk[0]);
+                        pk[1] = fma(ma.x, R2, pk[1]);
+                        pk[2] = fma(ma.y, R3, pk[2]);
+                        pk[3] = fma(mb.x, R4, pk[3]);
+                        pk[4] = fma(mb.y, R4 * R, pk[4]);
+                        pk[5] = fma(mc.x, R4 * R2, pk[5]);
+                        pk[6] = fma(mc.y, R4 * R3, pk[6]);
+                        pk[7] = fma(md.x, R4 * R4, pk[7]);
+                    };
+                    for (int s = 0; s < n_occ; s += 2) {
+                        need();
+                        const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
+                        const bool two = s + 1 < n_occ;
+                        const ScratchEnt ua = rp[0], ub = rp[two ? PREP_MOM : 0];
+                        const double Ra = loadR(ua.ro), Rb2 = loadR(ub.ro);
+                        const double2 *qa = reinterpret_cast<const double2 *>(rp + 1);
+                        const double2 a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
+                        fold(ua.e, a0, a1, a2, a3, Ra);
+                        if (two) {
+                            const double2 *qb = reinterpret_cast<const double2 *>(rp + PREP_MOM + 1);
+                            const double2 b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3];
+                            fold(ub.e, b0, b1, b2, b3, Rb2);
+                        }
+                        pos += two ? 2 * PREP_MOM : PREP_MOM;
+                    }
+                    need();
+                    spend(2 + (int)((float)(nfar_tot + nrmax) * P.far_bits));
+#pragma unroll
+                    for (int k = 0; k < FAR_ORDER; ++k) pk[k] *= FAR_W[k];
+                    int l = 0;
+                    double rag_e = 0.0, rag_R = 0.0;
+                    if (rag) {
+                        const ScratchEnt en = ring[pos & (RING_UNITS - 1)];
+                        rag_e = en.e;
+                        rag_R = loadR(en.ro);
+                    }
+#pragma unroll
+                    for (int w = 0; w < J; w += 2) {
+                        double arg[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int j = dir > 0 ? w + u : J - 1 - (w + u);
+                            if (rag) {
+                                const int nj = __builtin_amdgcn_readlane(nrag_v, j);
+                                for (; l < nj; ++l) {
+                                    const double v = rag_e * rag_R, v2 = v * v;
+                                    const ScratchEnt en = ring[(pos + l + 1) & (RING_UNITS - 1)];     // one step ahead (the guard at the end)
+                                    rag_e = en.e;
+                                    rag_R = loadR(en.ro);
+                                    pk[0] += v;
+                                    pk[1] = fma(v2, 0.5, pk[1]);
+                                    pk[2] = fma(v2 * v, 0.3333333333333333, pk[2]);
+                                }
+                            }
+                            const double f = F[j];
+                            double t = pk[FAR_ORDER - 1];
+#pragma unroll
+                            for (int k = FAR_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
+                            arg[u] = -f * t;
+                        }
+                        const int j0 = dir > 0 ? w : J - 1 - w, j1 = dir > 0 ? w + 1 : J - 2 - w;
+                        double e0, e1;
+                        exp_neg2(arg[0], arg[1], e0, e1);
+                        acc[j0] *= e0;
+                        acc[j1] *= e1;
+                        asm volatile("" : "+v"(acc[j0]), "+v"(acc[j1]));
+                    }
+                    if (rag) pos += nrmax + PREP_RAG_GUARD;
+                }
+                return base_end;
+            };
+
+            // sites between / at the test sites (and any part of the windows not covered by bulk)
+            if (BMX_MIDTRI && mid_tri && A * (tL - t0) <= P.zcut) {
+                const double xk = A * (tj - t0);
+                double Gk, Hk;
+                exp_neg2(xk, -xk, Gk, Hk);
+                const int ro_k = mid_ro[jl];
+                spend((J - 1) * span_generic);
+                double Fs[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) Fs[j] = readlane_f64(Hk, j);
+                if (lane < J) scr[lane] = ScratchEnt{Gk, ro_k, 0};
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < J; i += 2) {
+                    const ScratchEnt en0 = scr[i], en1 = scr[i + 1];
+                    const double v1 = en1.e * loadR(en1.ro);
+                    if (i > 0) {
+                        const double v0 = en0.e * loadR(en0.ro);
+                        const double sv = v0 + v1, qv = v0 * v1;
+#pragma unroll
+                        for (int j = 0; j < i; ++j) acc[j] *= fma(Fs[j], fma(Fs[j], qv, sv), 1.0);
+                    }
+                    acc[i] *= fma(Fs[i], v1, 1.0);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < J; ++j) Fs[j] = readlane_f64(Gk, j);
+                if (lane < J) scr[lane] = ScratchEnt{Hk, ro_k, 0};
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < J; i += 2) {
+                    const ScratchEnt en0 = scr[i], en1 = scr[i + 1];
+                    const double v0 = en0.e * loadR(en0.ro);
+                    if (i + 2 < J) {
+                        const double v1 = en1.e * loadR(en1.ro);
+                        const double sv = v0 + v1, qv = v0 * v1;
+#pragma unroll
+                        for (int j = i + 2; j < J; ++j) acc[j] *= fma(Fs[j], fma(Fs[j], qv, sv), 1.0);
+                    }
+                    acc[i + 1] *= fma(Fs[i + 1], v0, 1.0);
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                for (int b = L_int; b < R_int; b += SP) generic_pass(b, +1, R_int, staged);
+            }
+            // right side
+            int b = bulk_zone(+1, tL);
+            if (b != PREP_ZONE_DONE) { while (!generic_pass(b, +1, N, false)) b += SP; }
+            // left side
+            b = bulk_zone(-1, t0);
+            if (b != PREP_ZONE_DONE) { while (!generic_pass(b, -1, -1, false)) b -= SP; }
+
+            renorm_all();
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int ec = min(max(E[j], -131071), 131071) + 131072;
+                const int eb = bestK[j] >> 13;
+                const bool better = (ec > eb) || (ec == eb && acc[j] > bestM[j]);
+                if (better && p < P.npairs) {
+                    bestM[j] = acc[j];
+                    bestK[j] = (ec << 13) | iA;
+                }
+            }
+            if (bad) break;
+        }
+        if (bad && lane == 0) atomicOr(V.status, 2);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int biA = bestK[j] & 8191;
+            int bE = bestK[j] >> 13;
+            double bM = bestM[j];
+            int bL = (biA == 8191 || bad) ? 0x7fffffff : biA * P.npairs + p;
+            for (int off = 32; off > 0; off >>= 1) {
+                const int oE = __shfl_xor(bE, off);
+                const double oM = __shfl_xor(bM, off);
+                const int oL = __shfl_xor(bL, off);
+                if (oE > bE || (oE == bE && (oM > bM || (oM == bM && oL < bL)))) { bE = oE; bM = oM; bL = oL; }
+            }
+            if (lane == 0 && j < nvalid) {
+                const size_t o = (size_t)slice * P.M + (tb + j);
+                P.part_T[o] = bM;
+                P.part_lin[o] = bL;
+                P.part_ns[o] = bE;
+            }
+        }
+    }
+}
+
 // Combine the per-slice winners of a test site, take the one logarithm, and count nSites of the winning A
 // (the scan kernels do not carry window sizes).  The count uses the scan's exact predicate:
 // i in [lo,hi], A*|g_i - t| <= zcut, g_i != t; it is monotone on either side of the test site.
@@ -1489,12 +2329,83 @@ void parallel_ranges(int64_t n, int64_t grain, F fn) {
 
 }  // namespace
 
+struct ScanPlan;
+
+// One launch range of the prepared pipeline: test sites [off, off + cnt) = groups [g0, g0 + ng), whose blobs take `units`
+// 16-byte units of the arena starting at prefix `pbase`.
+struct PrepRange {
+    int64_t off, cnt, g0, ng, pbase, units;
+};
+
+// Everything a launch of the scan needs that does not depend on which test sites it covers.
+struct ScanPlan {
+    ScanParams P;
+    const void *fn = nullptr;
+    int J = 0, threads = SCAN_THREADS;
+    size_t lds_bytes = 0;
+    int spb = 0;            // test sites per workgroup
+    int64_t range = 0;      // test sites per launch (multiple of spb): bounds the per-slice winner arrays
+    bool use_lds = false;
+    int mode = 3;           // inner-loop form of the grouped kernel (0..3), 4: prepared pipeline
+    // prepared pipeline (mode 4): the per-group kernel's two forms and its launch shape
+    const void *prep_count = nullptr, *prep_fill = nullptr;
+    size_t prep_lds = 0;
+    int thr_in_lds = 0;
+};
+
+// One chromosome of a context (a "slot"): its site arrays, its test sites, their results and the scan plan made for them.
+// A context holds ONE model and any number of slots (bmx_ctx_select_slot); a whole-genome run keeps every chromosome
+// resident and scans them back to back on the context's stream.
+struct ChromSlot {
+    // sites (grow-only buffers)
+    bool has_sites = false;
+    int64_t N = 0;
+    DevBuf<double> genpos, rowmax, rowthr;
+    DevBuf<uint16_t> row16;      // one of the two is used
+    DevBuf<uint32_t> row32;
+    bool wide_rows = false;
+    DevBuf<uint8_t> kmom;        // far-field moment slots that pay at each A (set_sites)
+    DevBuf<int> d_row_of_slot;
+    int row_of_slot[MOM_SLOTS] = {0};
+    int nslots = 0;              // rows ranked by frequency: row_of_slot[0 .. nslots)
+    // tests
+    bool has_tests = false;
+    int64_t M = 0;
+    DevBuf<double> test_gen;
+    DevBuf<int64_t> win_lo, win_hi, center, center_hi;
+    bool tests_sorted = false;
+    int64_t test_gap = 1 << 30;  // median index gap between neighbouring test sites (strided sample of all of them)
+    // results of all test sites
+    bool timed = false;          // a scan has been launched since the test sites were set: results / events are valid
+    DevBuf<double> clr;
+    DevBuf<int32_t> lin, nsites;
+    DevBuf<bmx_record> rec;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // plan of the scan, made once per (model, sites, tests, variant)
+    bool plan_ok = false;
+    int plan_variant = -1;
+    ScanPlan plan;
+    // prepared pipeline: blob sizes per group, their exclusive prefix, launch ranges
+    bool prep_ok = false;
+    DevBuf<int32_t> blob_units;
+    DevBuf<int64_t> blob_prefix;
+    std::vector<PrepRange> ranges;
+
+    void release() {
+        genpos.release(); rowmax.release(); rowthr.release(); row16.release(); row32.release(); kmom.release(); d_row_of_slot.release();
+        test_gen.release(); win_lo.release(); win_hi.release(); center.release(); center_hi.release();
+        clr.release(); lin.release(); nsites.release(); rec.release();
+        blob_units.release(); blob_prefix.release();
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        ev0 = ev1 = nullptr;
+    }
+};
+
 struct bmx_ctx {
     int device = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
-    bool timed = false;         // a scan has been launched since the test sites were set: results / events are valid
     int variant = 0;
     // model
     bool has_model = false;
@@ -1509,37 +2420,23 @@ struct bmx_ctx {
     double *d_patch_y = nullptr;
     int n_patch = 0;
     std::vector<double> h_g;
-    // sites (grow-only buffers)
-    bool has_sites = false;
-    int64_t N = 0;
-    DevBuf<double> genpos, rowmax;
-    DevBuf<uint16_t> row16;      // one of the two is used
-    DevBuf<uint32_t> row32;
-    bool wide_rows = false;
-    DevBuf<uint8_t> kmom;        // far-field moment slots that pay at each A (set_sites)
-    int row_of_slot[MOM_SLOTS] = {0};
-    int nslots = 0;              // rows ranked by frequency: row_of_slot[0 .. nslots)
+    // chromosomes
+    std::vector<ChromSlot *> slots;      // slot 0 exists from creation; nullptr: never selected
+    ChromSlot *cur = nullptr;
+    int cur_index = 0;
     unsigned long long *d_prof = nullptr;   // -DBMX_PROFILE / -DBMX_COUNT builds
-    // tests
-    bool has_tests = false;
-    int64_t M = 0;
-    DevBuf<double> test_gen;
-    DevBuf<int64_t> win_lo, win_hi, center, center_hi;
-    bool tests_sorted = false;
-    int64_t test_gap = 1 << 30;  // median index gap between neighbouring test sites (sampled)
-    // per-slice winners of one launch range, results of all test sites
-    DevBuf<double> part_T;
+    // scratch shared by the slots (launches of one context are serialised on its stream)
+    DevBuf<double> part_T;       // per-slice winners of one launch range
     DevBuf<int32_t> part_lin, part_ns;
-    DevBuf<double> clr;
-    DevBuf<int32_t> lin, nsites;
-    DevBuf<bmx_record> rec;
+    DevBuf<ScratchEnt> arena;    // prepared pipeline: the blobs of one launch range
+    int *d_status = nullptr;     // ... and its error bits
     DevBuf<double> surf_T;
     DevBuf<int32_t> surf_ns;
+    DevBuf<int64_t> gap_sample;
     // pinned host staging of the streaming writer: two slots of (clr, lin, nsites)
     void *h_stage[2] = {nullptr, nullptr};
     size_t h_stage_cap = 0;
     double zcut = 0;
-    double last_ms = 0.0;
 };
 
 namespace {
@@ -1551,13 +2448,15 @@ void free_model(bmx_ctx *c) {
     c->has_model = false;
 }
 // sites / tests: the buffers stay allocated for the next chromosome; only the state is dropped
-void drop_tests(bmx_ctx *c) {
-    c->has_tests = false;
-    c->timed = false;       // results belong to the test sites they were computed for
+void drop_tests(ChromSlot *s) {
+    s->has_tests = false;
+    s->timed = false;       // results belong to the test sites they were computed for
+    s->plan_ok = false;
+    s->prep_ok = false;
 }
-void drop_sites(bmx_ctx *c) {
-    c->has_sites = false;
-    drop_tests(c);          // test sites were located in the old site array
+void drop_sites(ChromSlot *s) {
+    s->has_sites = false;
+    drop_tests(s);          // test sites were located in the old site array
 }
 
 template <class T>
@@ -1591,6 +2490,27 @@ int validate_model(const bmx_model *m) {
         if (!(m->x[i] > 0.0 && m->x[i] < 1.0)) return fail(BMX_E_INVALID, "model: x grid must lie in (0,1)");
     for (int i = 0; i < m->nab; i++)
         if (!(m->abeta[i] > 0.0)) return fail(BMX_E_INVALID, "model: alpha_beta grid must be positive");
+    return BMX_OK;
+}
+
+constexpr int MAX_SLOTS = 4096;
+
+int ensure_plan(bmx_ctx *c, ChromSlot *s);
+
+int select_slot(bmx_ctx *c, int slot) {
+    if (slot < 0 || slot >= MAX_SLOTS) return fail(BMX_E_INVALID, "slot index out of range (0..4095)");
+    if ((size_t)slot >= c->slots.size()) c->slots.resize((size_t)slot + 1, nullptr);
+    if (!c->slots[(size_t)slot]) {
+        ChromSlot *s = new ChromSlot();
+        if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) {
+            s->release();
+            delete s;
+            return fail(BMX_E_HIP, "event creation failed");
+        }
+        c->slots[(size_t)slot] = s;
+    }
+    c->cur = c->slots[(size_t)slot];
+    c->cur_index = slot;
     return BMX_OK;
 }
 
@@ -1632,11 +2552,12 @@ int bmx_ctx_create(bmx_ctx **out, int device) {
     bmx_ctx *c = new bmx_ctx();
     c->device = device;
     c->zcut = compute_zcut();
-    bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipStreamCreate(&c->copy_stream) == hipSuccess &&
-              hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipStreamCreate(&c->copy_stream) == hipSuccess;
     for (int k = 0; ok && k < 2; k++)
         ok = hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_copied[k], hipEventDisableTiming) == hipSuccess;
+    if (ok) ok = hipMalloc((void **)&c->d_status, sizeof(int)) == hipSuccess && hipMemset(c->d_status, 0, sizeof(int)) == hipSuccess;
+    if (ok) ok = select_slot(c, 0) == BMX_OK;
     if (!ok) {
         bmx_ctx_destroy(c);
         return fail(BMX_E_HIP, "stream/event creation failed");
@@ -1652,19 +2573,18 @@ void bmx_ctx_destroy(bmx_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     free_model(c);
-    c->genpos.release(); c->rowmax.release(); c->row16.release(); c->row32.release(); c->kmom.release();
-    c->test_gen.release(); c->win_lo.release(); c->win_hi.release(); c->center.release(); c->center_hi.release();
-    c->part_T.release(); c->part_lin.release(); c->part_ns.release();
-    c->clr.release(); c->lin.release(); c->nsites.release(); c->rec.release();
+    for (ChromSlot *s : c->slots)
+        if (s) { s->release(); delete s; }
+    c->slots.clear();
+    c->part_T.release(); c->part_lin.release(); c->part_ns.release(); c->arena.release(); c->gap_sample.release();
     c->surf_T.release(); c->surf_ns.release();
     dfree(c->d_prof);
+    dfree(c->d_status);
     for (int k = 0; k < 2; k++) {
         if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
         if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
         if (c->ev_copied[k]) (void)hipEventDestroy(c->ev_copied[k]);
     }
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
@@ -1674,6 +2594,17 @@ int bmx_ctx_set_variant(bmx_ctx *c, int variant) {
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
     c->variant = variant;
     return BMX_OK;
+}
+
+int bmx_ctx_select_slot(bmx_ctx *c, int32_t slot) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    return select_slot(c, slot);
+}
+
+int bmx_ctx_slot_count(bmx_ctx *c) {
+    if (!c) return 0;
+    return (int)c->slots.size();
 }
 
 int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t nA) {
@@ -1687,7 +2618,8 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_model(c);
-    drop_sites(c);      // row indices and the moment slots belong to the model they were set under
+    for (ChromSlot *s : c->slots)
+        if (s) drop_sites(s);      // row indices and the moment slots belong to the model they were set under
     c->stat = m->stat; c->min_count = m->min_count; c->n_sizes = m->n_sizes;
     c->rows = m->row_off[m->n_sizes]; c->nx = m->nx; c->nab = m->nab; c->nA = nA;
     c->npairs = m->nx * m->nab;
@@ -1801,6 +2733,7 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
     if (!c->has_model) return fail(BMX_E_STATE, "set_model must precede set_sites");
     if (N < 1 || !genpos || !row) return fail(BMX_E_INVALID, "empty site arrays");
     if (N >= 0x7fffffffLL) return fail(BMX_E_LIMIT, "more than 2^31 sites in one array (scan chromosomes one at a time)");
+    ChromSlot *s = c->cur;
     // One pass on the host's cores: every row index inside the table and on a (k, n) with a positive neutral probability
     // (the kernels index the LDS/L2 table with it unchecked), positions sorted and not NaN; 16-bit row indices and the
     // per-row site counts (moment slots) come out of the same pass.
@@ -1808,42 +2741,44 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
     std::vector<uint16_t> r16(wide ? 0 : (size_t)N);
     std::vector<uint32_t> r32(wide ? (size_t)N : 0);
     constexpr int MAXT = 32;
-    int bad[MAXT];
+    std::atomic<int> bad{0};             // first kind of fault seen by any thread (which one wins does not matter)
     std::vector<int64_t> cnt_t[MAXT];
-    for (int t = 0; t < MAXT; t++) bad[t] = 0;
     parallel_ranges(N, 1 << 18, [&](int t, int64_t b, int64_t e) {
         std::vector<int64_t> &cnt = cnt_t[t];
         cnt.assign((size_t)c->rows, 0);
         for (int64_t i = b; i < e; i++) {
             const int32_t r = row[i];
-            if (r < 0 || r >= c->rows) { bad[t] = 1; return; }
-            if (!(c->h_g[(size_t)r] > 0.0)) { bad[t] = 2; return; }
-            if (i && genpos[i] < genpos[i - 1]) { bad[t] = 3; return; }
-            if (!(genpos[i] == genpos[i])) { bad[t] = 4; return; }
+            int f = 0;
+            if (r < 0 || r >= c->rows) f = 1;
+            else if (!(c->h_g[(size_t)r] > 0.0)) f = 2;
+            else if (i && genpos[i] < genpos[i - 1]) f = 3;
+            else if (!(genpos[i] == genpos[i])) f = 4;
+            if (f) { bad.store(f, std::memory_order_relaxed); return; }
             if (wide) r32[(size_t)i] = (uint32_t)r; else r16[(size_t)i] = (uint16_t)r;
             cnt[(size_t)r]++;
         }
     });
-    for (int t = 0; t < MAXT; t++) {
-        if (bad[t] == 1) return fail(BMX_E_INVALID, "site row index outside the LUT");
-        if (bad[t] == 2) return fail(BMX_E_INVALID, "a site has a (count, sample size) whose neutral probability is missing or not positive");
-        if (bad[t] == 3) return fail(BMX_E_INVALID, "genetic positions must be non-decreasing");
-        if (bad[t] == 4) return fail(BMX_E_INVALID, "NaN genetic position");
+    switch (bad.load()) {
+        case 1: return fail(BMX_E_INVALID, "site row index outside the LUT");
+        case 2: return fail(BMX_E_INVALID, "a site has a (count, sample size) whose neutral probability is missing or not positive");
+        case 3: return fail(BMX_E_INVALID, "genetic positions must be non-decreasing");
+        case 4: return fail(BMX_E_INVALID, "NaN genetic position");
+        default: break;
     }
     std::vector<int64_t> cnt((size_t)c->rows, 0);
     for (int t = 0; t < MAXT; t++)
         for (size_t r = 0; r < cnt_t[t].size(); r++) cnt[r] += cnt_t[t][r];
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    drop_sites(c);
+    drop_sites(s);
     int rc;
-    if ((rc = upload(c->genpos, genpos, (size_t)N, c->stream))) return rc;
+    if ((rc = upload(s->genpos, genpos, (size_t)N, c->stream))) return rc;
     if (wide) {
-        if ((rc = upload(c->row32, (const uint32_t *)r32.data(), (size_t)N, c->stream))) return rc;
+        if ((rc = upload(s->row32, (const uint32_t *)r32.data(), (size_t)N, c->stream))) return rc;
     } else {
-        if ((rc = upload(c->row16, (const uint16_t *)r16.data(), (size_t)N, c->stream))) return rc;
+        if ((rc = upload(s->row16, (const uint16_t *)r16.data(), (size_t)N, c->stream))) return rc;
     }
-    c->wide_rows = wide;
+    s->wide_rows = wide;
     {
         // Moment slots for the grouped kernel's far field: rank the rows by how many sites carry them.
         // Slot s pays at a given A when the ~23 instructions saved per far site of that row outweigh
@@ -1859,11 +2794,11 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
         for (size_t k = 0; k < ns; k++) {
             if (cnt[(size_t)order[k]] == 0) break;
             slot[(size_t)order[k]] = (uint8_t)k;
-            c->row_of_slot[k] = order[k];
+            s->row_of_slot[k] = order[k];
             nslots = (int)k + 1;
         }
-        for (int k = nslots; k < MOM_SLOTS; k++) c->row_of_slot[k] = nslots ? c->row_of_slot[0] : 0;
-        c->nslots = nslots;
+        for (int k = nslots; k < MOM_SLOTS; k++) s->row_of_slot[k] = nslots ? s->row_of_slot[0] : 0;
+        s->nslots = nslots;
         const int kcap = diag_env("BMX_MOM_SLOTS") ? std::min(std::max(atoi(diag_env("BMX_MOM_SLOTS")), 0), MOM_SLOTS) : MOM_SLOTS;
         const double range = genpos[N - 1] - genpos[0];
         std::vector<uint8_t> km((size_t)c->nA, 0);
@@ -1871,7 +2806,7 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
             const double nfar = range > 0 ? 0.8 * (double)(N - 1) / range * c->zcut / c->h_A[(size_t)a] : (double)N;
             int k = 0;
             const double gain = diag_env("BMX_KMOM_GAIN") ? atof(diag_env("BMX_KMOM_GAIN")) : 23.0;      // threshold experiments
-            while (k < nslots && k < kcap && (double)cnt[(size_t)c->row_of_slot[k]] / (double)N * nfar * gain > 30.0) k++;
+            while (k < nslots && k < kcap && (double)cnt[(size_t)s->row_of_slot[k]] / (double)N * nfar * gain > 30.0) k++;
             km[(size_t)a] = (uint8_t)k;
         }
         // the kernel reads max |R| and the slot of a row with one load: the slot sits in the low mantissa
@@ -1895,79 +2830,101 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
             bits = ((bits & ~0xffull) + 0x100ull) | slot[k % (size_t)c->rows];
             memcpy(&packed[k], &bits, sizeof bits);
         }
-        if ((rc = upload(c->rowmax, (const double *)packed.data(), packed.size(), c->stream))) return rc;
-        if ((rc = upload(c->kmom, (const uint8_t *)km.data(), km.size(), c->stream))) return rc;
+        if ((rc = upload(s->rowmax, (const double *)packed.data(), packed.size(), c->stream))) return rc;
+        if ((rc = upload(s->kmom, (const uint8_t *)km.data(), km.size(), c->stream))) return rc;
+        // prepared pipeline: ONE far threshold per row for all slices, in the exponent domain -- a site of the row at
+        // z = A d >= thr has alpha max_grid|R| <= far_eps (log rounded up, the low mantissa byte replaced by the row's slot
+        // after rounding up once more).  Rows with max|R| <= far_eps / e are far at any distance (thr = -1); rows absent from
+        // the helper file (max|R| = inf) get NaN, which never compares as far.
+        const double eps = FAR_ORDER >= 8 ? 0.05 : FAR_ORDER >= 6 ? 0.0105 : 0.0016;
+        std::vector<double> thr((size_t)c->rows);
+        const size_t R_ = (size_t)c->rows, S_ = c->h_rowmax.size() / std::max<size_t>(R_, 1);
+        for (size_t r = 0; r < R_; r++) {
+            double m = 0.0;
+            for (size_t sl = 0; sl < S_; sl++) {
+                const double v = c->h_rowmax[sl * R_ + r];
+                m = (v != v || m != m) ? NAN : std::max(m, v);
+            }
+            double t = (m != m) ? INFINITY : (m <= eps * 0.36) ? -1.0 : std::log(m / eps) * (1.0 + 1e-12) + 1e-9;
+            if (t < 0.0 && t != -1.0) t = std::max(t, -1.0);
+            uint64_t bits;
+            memcpy(&bits, &t, sizeof bits);
+            if (t > 0.0) bits = ((bits & ~0xffull) + 0x100ull) | slot[r];     // rounds the threshold up; +inf becomes NaN
+            else bits = (bits & ~0xffull) | slot[r];                            // negative: far at any distance either way
+            memcpy(&thr[r], &bits, sizeof bits);
+        }
+        if ((rc = upload(s->rowthr, (const double *)thr.data(), thr.size(), c->stream))) return rc;
+        if ((rc = upload(s->d_row_of_slot, (const int *)s->row_of_slot, (size_t)MOM_SLOTS, c->stream))) return rc;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));     // the staging vectors go out of scope here
-    c->N = N;
-    c->has_sites = true;
+    s->N = N;
+    s->has_sites = true;
     return BMX_OK;
 }
 
 int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64_t *win_lo,
                       const int64_t *win_hi) {
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
-    if (!c->has_sites) return fail(BMX_E_STATE, "set_sites must precede set_tests");
+    ChromSlot *s = c->cur;
+    if (!s->has_sites) return fail(BMX_E_STATE, "set_sites must precede set_tests");
     if (M < 1 || !test_gen || !win_lo || !win_hi) return fail(BMX_E_INVALID, "empty test-site arrays");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    drop_tests(c);
+    drop_tests(s);
     int rc;
-    if ((rc = upload(c->test_gen, test_gen, (size_t)M, c->stream))) return rc;
-    if ((rc = upload(c->win_lo, win_lo, (size_t)M, c->stream))) return rc;
-    if ((rc = upload(c->win_hi, win_hi, (size_t)M, c->stream))) return rc;
-    HIP_TRY(c->center.ensure((size_t)M));
-    HIP_TRY(c->center_hi.ensure((size_t)M));
-    HIP_TRY(c->clr.ensure((size_t)M));
-    HIP_TRY(c->lin.ensure((size_t)M));
-    HIP_TRY(c->nsites.ensure((size_t)M));
-    HIP_TRY(c->rec.ensure((size_t)M));
+    if ((rc = upload(s->test_gen, test_gen, (size_t)M, c->stream))) return rc;
+    if ((rc = upload(s->win_lo, win_lo, (size_t)M, c->stream))) return rc;
+    if ((rc = upload(s->win_hi, win_hi, (size_t)M, c->stream))) return rc;
+    HIP_TRY(s->center.ensure((size_t)M));
+    HIP_TRY(s->center_hi.ensure((size_t)M));
+    HIP_TRY(s->clr.ensure((size_t)M));
+    HIP_TRY(s->lin.ensure((size_t)M));
+    HIP_TRY(s->nsites.ensure((size_t)M));
+    HIP_TRY(s->rec.ensure((size_t)M));
     int threads = 256;
     hipLaunchKernelGGL(locate_kernel, dim3((unsigned)((M + threads - 1) / threads)), dim3(threads), 0, c->stream,
-                       c->genpos.p, c->N, c->test_gen.p, M, c->center.p, c->center_hi.p);
+                       s->genpos.p, s->N, s->test_gen.p, M, s->center.p, s->center_hi.p);
     HIP_TRY(hipGetLastError());
-    // while the device locates the test sites: the grouped kernel needs ascending test positions
-    int unsorted = 0;
+    // test-site density: the median index gap between neighbouring test sites over a strided sample of ALL of them (decides
+    // grouped vs per-site kernel and the group size; a chromosome whose head differs from its body is judged by its body)
+    const int64_t ns = std::min<int64_t>(M - 1, 65536);
+    if (ns > 0) {
+        HIP_TRY(c->gap_sample.ensure((size_t)ns));
+        hipLaunchKernelGGL(gap_kernel, dim3((unsigned)((ns + threads - 1) / threads)), dim3(threads), 0, c->stream,
+                           s->center.p, (M - 1) / ns, ns, c->gap_sample.p);
+        HIP_TRY(hipGetLastError());
+    }
+    // while the device locates the test sites: the grouped kernels need ascending test positions
+    std::atomic<int> unsorted{0};
     parallel_ranges(M, 1 << 18, [&](int, int64_t b, int64_t e) {
         for (int64_t t = std::max<int64_t>(b, 1); t < e; t++)
-            if (!(test_gen[t] >= test_gen[t - 1])) { unsorted = 1; return; }
+            if (!(test_gen[t] >= test_gen[t - 1])) { unsorted.store(1, std::memory_order_relaxed); return; }
     });
-    c->tests_sorted = !unsorted;
-    {   // test-site density from a sample of the located positions (decides grouped vs per-site kernel)
-        const int64_t ns = std::min<int64_t>(M, 65536);
-        std::vector<int64_t> hc((size_t)ns);
-        HIP_TRY(hipMemcpyAsync(hc.data(), c->center.p, (size_t)ns * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    s->tests_sorted = !unsorted.load();
+    s->test_gap = 1 << 30;
+    if (ns > 0) {
+        std::vector<int64_t> gaps((size_t)ns);
+        HIP_TRY(hipMemcpyAsync(gaps.data(), c->gap_sample.p, (size_t)ns * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        std::vector<int64_t> gaps;
-        for (int64_t t = 1; t < ns; t++) gaps.push_back(hc[(size_t)t] - hc[(size_t)t - 1]);
-        c->test_gap = 1 << 30;
-        if (!gaps.empty()) {
-            std::nth_element(gaps.begin(), gaps.begin() + gaps.size() / 2, gaps.end());
-            c->test_gap = gaps[gaps.size() / 2];
-        }
+        std::nth_element(gaps.begin(), gaps.begin() + gaps.size() / 2, gaps.end());
+        s->test_gap = gaps[gaps.size() / 2];
+    } else {
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    c->M = M;
-    c->has_tests = true;
-    return BMX_OK;
+    s->M = M;
+    s->has_tests = true;
+    // the plan of the scan, and for the prepared pipeline the sizes of its per-group blobs (a counting pass on the device),
+    // are part of setting the test sites: bmx_ctx_scan itself only launches
+    return ensure_plan(c, s);
 }
 
 }  // extern "C"
 
 namespace {
 
-// Everything a launch of the scan needs that does not depend on which test sites it covers.
-struct ScanPlan {
-    ScanParams P;
-    const void *fn = nullptr;
-    int J = 0, threads = SCAN_THREADS;
-    size_t lds_bytes = 0;
-    int spb = 0;            // test sites per workgroup
-    int64_t range = 0;      // test sites per launch (multiple of spb): bounds the per-slice winner arrays
-};
-
-int plan_scan(bmx_ctx *c, ScanPlan &pl) {
+int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
     ScanParams &P = pl.P;
-    P.genpos = c->genpos.p; P.row = RowArray{c->wide_rows ? nullptr : c->row16.p, c->wide_rows ? c->row32.p : nullptr}; P.N = c->N; P.Rt = c->d_Rt;
+    P.genpos = s->genpos.p; P.row = RowArray{s->wide_rows ? nullptr : s->row16.p, s->wide_rows ? s->row32.p : nullptr}; P.N = s->N; P.Rt = c->d_Rt;
     P.rows = c->rows; P.NP = c->NP; P.npairs = c->npairs; P.nslices = c->nslices;
     P.A = c->d_A; P.nA = c->nA; P.zcut = c->zcut; P.renorm_every = c->renorm_every; P.span_hi = c->span_hi; P.rmax = c->rmax;
     {
@@ -1976,79 +2933,86 @@ int plan_scan(bmx_ctx *c, ScanPlan &pl) {
         double eps = diag_env("BMX_FAR_EPS") ? atof(diag_env("BMX_FAR_EPS")) : eps_default;   // accuracy experiments
         eps = std::min(std::max(eps, 0.0), FAR_ORDER >= 8 ? 0.05 : 0.035);
         P.far_eps = eps;
-        P.rowmax = c->rowmax.p;
-        P.kmom = c->kmom.p;
+        P.rowmax = s->rowmax.p;
+        P.kmom = s->kmom.p;
         P.prof = nullptr;
 #if defined(BMX_PROFILE) || defined(BMX_COUNT)
         if (!c->d_prof) { HIP_TRY(hipMalloc((void **)&c->d_prof, 32 * sizeof(unsigned long long))); HIP_TRY(hipMemset(c->d_prof, 0, 32 * sizeof(unsigned long long))); }
         P.prof = c->d_prof;
 #endif
-        for (int k = 0; k < MOM_SLOTS; k++) P.row_of_slot[k] = c->row_of_slot[k];
+        for (int k = 0; k < MOM_SLOTS; k++) P.row_of_slot[k] = s->row_of_slot[k];
         P.far_bits = (float)(eps * 1.4427 * 1.03);      // |log1p(x)| <= 1.027 |x| for |x| <= 0.05
     }
     size_t lds = (size_t)c->rows * WAVE * sizeof(double);
     if (const char *pad = diag_env("BMX_LDS_PAD")) lds += (size_t)std::max(atoi(pad), 0);   // occupancy experiments
-    // moment slots per wave: as many (64, 32, 16, 8, 0) as leave the R slice in LDS; when the table is
-    // too large for LDS anyway (many sample sizes: the sites spread over many rows), all MOM_SLOTS
-    int mom_slots = MOM_SLOTS_LDS;
-    auto wave_bytes = [&](int slots) {
-        return SCR_CAP * sizeof(ScratchEnt) + (size_t)(slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double) + (size_t)MID_CAP * 12;
-    };
-    auto lds_need = [&](int slots) {
-        return lds + (size_t)(c->rows + 2) * sizeof(double) + (size_t)(SCAN_THREADS_MAX / WAVE) * wave_bytes(slots);
-    };
-    while (mom_slots >= 8 && lds_need(mom_slots) > (size_t)LDS_LIMIT_BYTES) mom_slots /= 2;
-    if (mom_slots < 8) mom_slots = 0;
-    const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES && !diag_env("BMX_NO_LDS");   // BMX_NO_LDS: R from L2 (A/B runs)
-    if (!fits || c->variant == 1) mom_slots = MOM_SLOTS;
-    P.mom_slots = mom_slots;
-    P.row0 = c->nslots > 0 ? c->row_of_slot[0] : -1;
+    P.row0 = s->nslots > 0 ? s->row_of_slot[0] : -1;
     P.wide_tab = (size_t)c->rows * c->NP * sizeof(double) >= ((size_t)1 << 32) ? 1 : 0;
-    // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3 at HEAD
+    // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3 in round 2
     // (windows/s x1000 for J = 16 / 8 / 4 / per-site; profiles/r02_stride_table.txt): stride 1: 3005/2108/1250/-,
     // 2: 2585/1989/1229, 3: 2115/1880/1203, 4: 1691/1780/1177, 8: 1146/1391/1075, 16: 755/1014/910, 32: 477/706/720/590,
     // 48: 341/548/611/575, 64: 276/464/536/569, 128: 140/282/374/523 -> J by the median gap between test sites;
     // beyond ~56 sites the per-site kernel takes over.
     const int64_t gap_max = diag_env("BMX_DENSE_GAP") ? atoll(diag_env("BMX_DENSE_GAP")) : 56;
-    const bool can_group = c->tests_sorted && c->test_gap <= gap_max && c->span_hi <= 62 && c->N < 0x7fffffffLL && c->nA < 8191 && !P.wide_tab;
+    const bool can_group = s->tests_sorted && s->test_gap <= gap_max && c->span_hi <= 62 && s->N < 0x7fffffffLL && c->nA < 8191 && !P.wide_tab;
     int J = 0;
-    // variants (A/B runs): 0 -> J by test-site gap, pairs near / quads mid / power sums far (default);
+    // variants: 0 -> prepared pipeline (round 3: per-group work done once by prep_kernel), J by test-site gap;
+    //           13 / 14 / 15 -> prepared, J = 16 / 8 / 4;
+    //           12 -> the round-2 grouped kernel, J by test-site gap (pairs near / quads mid / power sums far);
     //           3 -> J=8, 4 -> J=4 (same form); 10/11 -> J=16/8 without the power sums (exact products);
     //           8/9 -> J=16/8 pairs only; 5/6/7 -> J=16/8/4 readlane single-site loop; 1, 2 -> per-site kernel
+    const int v = c->variant;
+    const bool prepared = can_group && (v == 0 || (v >= 13 && v <= 15)) && FAR_ORDER == 8 && !diag_env("BMX_FAR_EPS");
     if (can_group) {
-        const int v = c->variant;
-        J = (v == 0 || v == 5 || v == 8 || v == 10) ? 16 : (v == 3 || v == 6 || v == 9 || v == 11) ? 8 : (v == 4 || v == 7) ? 4 : 0;
-        if (v == 0) J = c->test_gap <= 3 ? 16 : c->test_gap <= 28 ? 8 : 4;
-        if (v == 0 && diag_env("BMX_FORCE_J")) {                                  // threshold experiments: 16, 8 or 4
+        J = (v == 0 || v == 12 || v == 5 || v == 8 || v == 10 || v == 13) ? 16 : (v == 3 || v == 6 || v == 9 || v == 11 || v == 14) ? 8
+            : (v == 4 || v == 7 || v == 15) ? 4 : 0;
+        if (v == 0 || v == 12) J = s->test_gap <= 3 ? 16 : s->test_gap <= 28 ? 8 : 4;
+        if ((v == 0 || v == 12) && diag_env("BMX_FORCE_J")) {                    // threshold experiments: 16, 8 or 4
             const int fj = atoi(diag_env("BMX_FORCE_J"));
             if (fj != 16 && fj != 8 && fj != 4) return fail(BMX_E_INVALID, "BMX_FORCE_J must be 16, 8 or 4");
             J = fj;
         }
     }
-    int spb = J ? (c->M >= 65536 ? 64 : 4 * J) : (c->M >= 65536 ? 32 : SITE_THREADS / WAVE);   // per-site kernel: >= one test site per wave
+    // LDS: the prepared kernel keeps per wave a ring of the blob stream and 512 B of scratch, the round-2 grouped kernel a
+    // scratch list and the moments; both the sites between the test sites; the slice's per-row max |R| only the latter
+    int mom_slots = MOM_SLOTS_LDS;
+    auto wave_bytes = [&](int slots) {
+        if (prepared) return (size_t)(RING_UNITS + RING_MIRROR + AUX_UNITS) * sizeof(ScratchEnt) + (size_t)MID_CAP * 12;
+        return SCR_CAP * sizeof(ScratchEnt) + (size_t)(slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double) + (size_t)MID_CAP * 12;
+    };
+    const size_t lds_rm = prepared ? 0 : (size_t)((c->rows + 1) & ~1) * sizeof(double);
+    auto lds_need = [&](int slots) { return lds + lds_rm + (size_t)(SCAN_THREADS_MAX / WAVE) * wave_bytes(slots); };
+    // moment slots: as many (64, 32, 16, 8, 0) as leave the R slice in LDS; when the table is too large for LDS anyway
+    // (many sample sizes: the sites spread over many rows), all MOM_SLOTS.  (The prepared pipeline's moments live in
+    // prep_kernel's LDS: 64 slots with the table in LDS, all of them otherwise -- the same rule, so that both forms
+    // classify alike.)
+    while (!prepared && mom_slots >= 8 && lds_need(mom_slots) > (size_t)LDS_LIMIT_BYTES) mom_slots /= 2;
+    if (mom_slots < 8) mom_slots = 0;
+    const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES && !diag_env("BMX_NO_LDS");   // BMX_NO_LDS: R from L2 (A/B runs)
+    if (!fits || c->variant == 1) mom_slots = MOM_SLOTS;
+    P.mom_slots = mom_slots;
+    int spb = J ? (s->M >= 65536 ? 64 : 4 * J) : (s->M >= 65536 ? 32 : SITE_THREADS / WAVE);   // per-site kernel: >= one test site per wave
     if (J == 16 && spb < 64) spb = 64;
     if (J && diag_env("BMX_SPB")) spb = std::max(4 * J, atoi(diag_env("BMX_SPB")) / (4 * J) * (4 * J));   // experiments
     const bool use_lds = fits && c->variant != 1;
     const void *fn = nullptr;
 #define PICK(K) (use_lds ? (const void *)K<true> : (const void *)K<false>)
     // inner-loop form: 0 readlane / one site per step; 1 LDS broadcast + pairs; 2 = 1 + four sites per
-    // step where alpha <= 1/2; 3 (default) = 2 + power sums where alpha*max|R| <= far_eps
-    const int mode = (c->variant >= 5 && c->variant <= 7) ? 0 : (c->variant >= 8 && c->variant <= 9) ? 1 : (c->variant >= 10 && c->variant <= 11) ? 2 : 3;
+    // step where alpha <= 1/2; 3 = 2 + power sums where alpha*max|R| <= far_eps; 4 = 3 with the per-group work prepared
+    const int mode = prepared ? 4 : (v >= 5 && v <= 7) ? 0 : (v >= 8 && v <= 9) ? 1 : (v >= 10 && v <= 11) ? 2 : 3;
 #define GP2(JJ, MM) (use_lds ? (const void *)clr_scan_grouped_kernel<JJ, true, MM> : (const void *)clr_scan_grouped_kernel<JJ, false, MM>)
-#define GPICK(JJ) (mode == 3 ? GP2(JJ, 3) : mode == 2 ? GP2(JJ, 2) : mode == 1 ? GP2(JJ, 1) : GP2(JJ, 0))
+#define GP4(JJ) (use_lds ? (const void *)clr_scan_prepared_kernel<JJ, true> : (const void *)clr_scan_prepared_kernel<JJ, false>)
+#define GPICK(JJ) (mode == 4 ? GP4(JJ) : mode == 3 ? GP2(JJ, 3) : mode == 2 ? GP2(JJ, 2) : mode == 1 ? GP2(JJ, 1) : GP2(JJ, 0))
     if (J == 8) fn = GPICK(8);
     else if (J == 16) fn = GPICK(16);
     else if (J == 4) fn = GPICK(4);
     else fn = PICK(clr_scan_kernel);
 #undef GP2
+#undef GP4
 #undef GPICK
 #undef PICK
     // One wave per SIMD issues FP64 at half rate (measured), so a workgroup whose LDS footprint
     // allows only one resident workgroup per CU gets 8 waves instead of 4.
     int threads = SCAN_THREADS;
-    // grouped kernels: per-row max |R| (+ moment slot) behind the slice, then per wave the scratch list, the moments
-    // and the staged sites between the test sites
-    const size_t lds_rm = (size_t)((c->rows + 1) & ~1) * sizeof(double);
     size_t lds_bytes = (use_lds ? lds + (J ? lds_rm : 0) : 0) + (J ? (size_t)(threads / WAVE) * wave_bytes(mom_slots) : 0);
     if (J && 2 * lds_bytes > (size_t)LDS_LIMIT_BYTES) {
         threads = SCAN_THREADS_MAX;
@@ -2062,39 +3026,163 @@ int plan_scan(bmx_ctx *c, ScanPlan &pl) {
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return fail(BMX_E_LIMIT, "LDS budget exceeded");
     if (lds_bytes) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     P.sites_per_block = spb;
-    pl.fn = fn; pl.J = J; pl.threads = threads; pl.lds_bytes = lds_bytes; pl.spb = spb;
+    pl.fn = fn; pl.J = J; pl.threads = threads; pl.lds_bytes = lds_bytes; pl.spb = spb; pl.use_lds = use_lds; pl.mode = J ? mode : -1;
     // test sites per launch: keeps the per-slice winners (16 B x slices per test site) within ~512 MB and the grid
     // within 2^31 workgroups; a multiple of the workgroup's share, so ranges cut the test sites where workgroups do
     int64_t range = std::max<int64_t>((int64_t)(512u << 20) / (16 * (int64_t)c->nslices), spb);
     range = std::min<int64_t>(range, (int64_t)0x7fffff00LL / c->nslices * spb);
     range = std::max<int64_t>(range / spb, 1) * spb;
     pl.range = range;
-    TRACE("scan plan: lds=%zu use_lds=%d span_hi=%d spb=%d J=%d threads=%d range=%lld", lds_bytes, (int)use_lds, c->span_hi, spb, J, threads, (long long)range);
+    if (prepared) {
+        pl.thr_in_lds = c->rows <= PREP_THR_LDS_MAX ? 1 : 0;
+        const int pm = use_lds ? MOM_SLOTS_LDS : MOM_SLOTS;      // the moment slots of prep_kernel (see above)
+        P.mom_slots = pm;
+        pl.prep_lds = ((pl.thr_in_lds ? (size_t)((c->rows + 1) & ~1) : 0) +
+                       (size_t)(PREP_THREADS / WAVE) * ((size_t)(pm + MOM_COPIES - 1 + 3) * FAR_ORDER + WAVE)) * sizeof(double);
+#define PP(JJ, FF) (const void *)prep_kernel<JJ, FF>
+        pl.prep_count = J == 16 ? PP(16, false) : J == 8 ? PP(8, false) : PP(4, false);
+        pl.prep_fill = J == 16 ? PP(16, true) : J == 8 ? PP(8, true) : PP(4, true);
+#undef PP
+        if (pl.prep_lds > (size_t)LDS_LIMIT_BYTES) return fail(BMX_E_LIMIT, "LDS budget of the preparation kernel exceeded");
+        HIP_TRY(hipFuncSetAttribute(pl.prep_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prep_lds));
+        HIP_TRY(hipFuncSetAttribute(pl.prep_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prep_lds));
+    }
+    TRACE("scan plan: lds=%zu use_lds=%d span_hi=%d spb=%d J=%d threads=%d range=%lld mode=%d", lds_bytes, (int)use_lds, c->span_hi, spb, J, threads,
+          (long long)range, pl.mode);
     return BMX_OK;
 }
 
+PrepParams prep_params(bmx_ctx *c, ChromSlot *s, const ScanPlan &pl) {
+    PrepParams Q;
+    Q.genpos = s->genpos.p; Q.row = pl.P.row; Q.N = s->N;
+    Q.rows = c->rows; Q.rowmul = pl.use_lds ? WAVE : c->NP;
+    Q.A = c->d_A; Q.nA = c->nA;
+    Q.test_gen = s->test_gen.p; Q.win_lo = s->win_lo.p; Q.win_hi = s->win_hi.p; Q.center = s->center.p; Q.center_hi = s->center_hi.p;
+    Q.M = s->M; Q.zcut = c->zcut;
+    Q.rowthr = s->rowthr.p; Q.thr_in_lds = pl.thr_in_lds;
+    Q.kmom = s->kmom.p; Q.row_of_slot = s->d_row_of_slot.p; Q.mom_slots = pl.P.mom_slots;
+    Q.g_begin = 0; Q.g_end = 0;
+    Q.blob_units = s->blob_units.p; Q.blob_prefix = s->blob_prefix.p; Q.prefix_base = 0;
+    Q.arena = c->arena.p; Q.status = c->d_status;
+    return Q;
+}
+
+// Prepared pipeline, once per (model, sites, tests, variant): the counting pass over all groups, the prefix of the blob
+// sizes, and the launch ranges -- cut where the per-slice winner arrays (pl.range) or the arena would overflow.
+int ensure_prep(bmx_ctx *c, ChromSlot *s) {
+    ScanPlan &pl = s->plan;
+    if (pl.mode != 4 || s->prep_ok) return BMX_OK;
+    const int J = pl.J;
+    const int64_t ngroups = (s->M + J - 1) / J;
+    HIP_TRY(s->blob_units.ensure((size_t)ngroups));
+    HIP_TRY(s->blob_prefix.ensure((size_t)ngroups + 1));
+    PrepParams Q = prep_params(c, s, pl);
+    Q.g_begin = 0; Q.g_end = ngroups;
+    const int gpw = PREP_THREADS / WAVE;
+    void *kargs[] = {&Q};
+    HIP_TRY(hipLaunchKernel(pl.prep_count, dim3((unsigned)((ngroups + gpw - 1) / gpw)), dim3(PREP_THREADS), kargs, pl.prep_lds, c->stream));
+    hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t *)s->blob_units.p, ngroups, s->blob_prefix.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<int64_t> pre((size_t)ngroups + 1);
+    HIP_TRY(hipMemcpyAsync(pre.data(), s->blob_prefix.p, pre.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // arena budget: a quarter of what is free now (plus what the arena already holds), at most 16 GiB
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const int64_t cap_units = (int64_t)(std::min<size_t>((free_b + c->arena.cap * sizeof(ScratchEnt)) / 4, (size_t)16 << 30) / sizeof(ScratchEnt));
+    const int64_t gstep = std::max<int64_t>(pl.spb / J, 1);       // groups per workgroup of the consumer
+    s->ranges.clear();
+    int64_t need = 0;
+    for (int64_t g0 = 0; g0 < ngroups;) {
+        int64_t g1 = g0;
+        while (g1 < ngroups) {
+            const int64_t g2 = std::min(g1 + gstep, ngroups);
+            if (g1 > g0 && ((g2 - g0) * J > pl.range || pre[(size_t)g2] - pre[(size_t)g0] > cap_units)) break;
+            g1 = g2;
+        }
+        const int64_t units = pre[(size_t)g1] - pre[(size_t)g0];
+        if (units > cap_units) return fail(BMX_E_LIMIT, "prepared scan: one workgroup's share of the stream does not fit the device memory left");
+        s->ranges.push_back(PrepRange{g0 * J, std::min(g1 * J, s->M) - g0 * J, g0, g1 - g0, pre[(size_t)g0], units});
+        need = std::max(need, units);
+        g0 = g1;
+    }
+    HIP_TRY(c->arena.ensure((size_t)need + 4 * WAVE));     // the consumer's read-ahead runs up to three chunks past a blob's end
+    TRACE("prepared: %lld groups, %.1f MB of blobs, %zu launch range(s), arena %.1f MB", (long long)ngroups, (double)pre[(size_t)ngroups] * 16e-6,
+          s->ranges.size(), (double)c->arena.cap * 16e-6);
+    s->prep_ok = true;
+    return BMX_OK;
+}
+
+int ensure_plan(bmx_ctx *c, ChromSlot *s) {
+    if (!s->plan_ok || s->plan_variant != c->variant) {
+        s->plan_ok = false;
+        s->prep_ok = false;
+        int rc = plan_scan(c, s, s->plan);
+        if (rc) return rc;
+        s->plan_ok = true;
+        s->plan_variant = c->variant;
+    }
+    return ensure_prep(c, s);
+}
+
 // scan + finalize of test sites [off, off + cnt) on the context's stream (asynchronous)
-int launch_range(bmx_ctx *c, ScanPlan &pl, int64_t off, int64_t cnt) {
-    ScanParams &P = pl.P;
+int launch_range(bmx_ctx *c, ChromSlot *s, ScanPlan &pl, int64_t off, int64_t cnt, const PrepRange *pr) {
+    ScanParams P = pl.P;
     const size_t np = (size_t)cnt * c->nslices;
     HIP_TRY(c->part_T.ensure(np));
     HIP_TRY(c->part_lin.ensure(np));
     HIP_TRY(c->part_ns.ensure(np));
-    P.test_gen = c->test_gen.p + off; P.win_lo = c->win_lo.p + off; P.win_hi = c->win_hi.p + off;
-    P.center = c->center.p + off; P.center_hi = c->center_hi.p + off; P.M = cnt;
+    P.test_gen = s->test_gen.p + off; P.win_lo = s->win_lo.p + off; P.win_hi = s->win_hi.p + off;
+    P.center = s->center.p + off; P.center_hi = s->center_hi.p + off; P.M = cnt;
     P.part_T = c->part_T.p; P.part_lin = c->part_lin.p; P.part_ns = c->part_ns.p;
     const int64_t blocks = (cnt + pl.spb - 1) / pl.spb * c->nslices;
-    void *kargs[] = {&P};
-    HIP_TRY(hipLaunchKernel(pl.fn, dim3((unsigned)blocks), dim3(pl.threads), kargs, pl.lds_bytes, c->stream));
+    if (pr) {
+        // the range's blobs: filled by the per-group kernel, then consumed by one wave per (group, slice)
+        if ((size_t)pr->units + 4 * WAVE > c->arena.cap) HIP_TRY(c->arena.ensure((size_t)pr->units + 4 * WAVE));
+        PrepParams Q = prep_params(c, s, pl);
+        Q.g_begin = pr->g0; Q.g_end = pr->g0 + pr->ng; Q.prefix_base = pr->pbase;
+        const int gpw = PREP_THREADS / WAVE;
+        void *qargs[] = {&Q};
+        HIP_TRY(hipLaunchKernel(pl.prep_fill, dim3((unsigned)((pr->ng + gpw - 1) / gpw)), dim3(PREP_THREADS), qargs, pl.prep_lds, c->stream));
+        PrepView V;
+        V.arena = c->arena.p; V.blob_prefix = s->blob_prefix.p; V.prefix_base = pr->pbase; V.grp_base = pr->g0; V.status = c->d_status;
+        void *kargs[] = {&P, &V};
+        HIP_TRY(hipLaunchKernel(pl.fn, dim3((unsigned)blocks), dim3(pl.threads), kargs, pl.lds_bytes, c->stream));
+    } else {
+        void *kargs[] = {&P};
+        HIP_TRY(hipLaunchKernel(pl.fn, dim3((unsigned)blocks), dim3(pl.threads), kargs, pl.lds_bytes, c->stream));
+    }
     FinalParams F;
     F.part_T = c->part_T.p; F.part_lin = c->part_lin.p; F.part_ns = c->part_ns.p;
-    F.nslices = c->nslices; F.npairs = c->npairs; F.M = cnt; F.N = c->N;
-    F.genpos = c->genpos.p; F.A = c->d_A; F.test_gen = P.test_gen; F.win_lo = P.win_lo; F.win_hi = P.win_hi;
+    F.nslices = c->nslices; F.npairs = c->npairs; F.M = cnt; F.N = s->N;
+    F.genpos = s->genpos.p; F.A = c->d_A; F.test_gen = P.test_gen; F.win_lo = P.win_lo; F.win_hi = P.win_hi;
     F.center = P.center; F.center_hi = P.center_hi; F.zcut = c->zcut;
-    F.clr = c->clr.p + off; F.lin = c->lin.p + off; F.nsites = c->nsites.p + off; F.rec = c->rec.p + off;
+    F.clr = s->clr.p + off; F.lin = s->lin.p + off; F.nsites = s->nsites.p + off; F.rec = s->rec.p + off;
     const int fthreads = 256;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((cnt + fthreads - 1) / fthreads)), dim3(fthreads), 0, c->stream, F);
     HIP_TRY(hipGetLastError());
+    return BMX_OK;
+}
+
+// the launch ranges of a slot's scan: the prepared pipeline's own, or plain cuts of pl.range test sites
+int scan_ranges(bmx_ctx *c, ChromSlot *s, std::vector<PrepRange> &out) {
+    int rc = ensure_plan(c, s);
+    if (rc) return rc;
+    out.clear();
+    if (s->plan.mode == 4) { out = s->ranges; return BMX_OK; }
+    for (int64_t off = 0; off < s->M; off += s->plan.range)
+        out.push_back(PrepRange{off, std::min(s->plan.range, s->M - off), 0, 0, 0, 0});
+    return BMX_OK;
+}
+
+// the device-side error bits of the prepared pipeline, checked wherever results leave the library
+int check_status(bmx_ctx *c) {
+    int st = 0;
+    HIP_TRY(hipMemcpy(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+        HIP_TRY(hipMemset(c->d_status, 0, sizeof(int)));
+        return fail(BMX_E_HIP, st & 1 ? "prepared scan: a group's stream differs in size from the counting pass" : "prepared scan: bad zone header in a group's stream");
+    }
     return BMX_OK;
 }
 
@@ -2104,16 +3192,38 @@ extern "C" {
 
 int bmx_ctx_scan(bmx_ctx *c) {
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
-    if (!c->has_model || !c->has_sites || !c->has_tests) return fail(BMX_E_STATE, "model, sites and tests must be set before scan");
+    ChromSlot *s = c->cur;
+    if (!c->has_model || !s->has_sites || !s->has_tests) return fail(BMX_E_STATE, "model, sites and tests must be set before scan");
     HIP_TRY(hipSetDevice(c->device));
-    ScanPlan pl;
-    int rc = plan_scan(c, pl);
+    std::vector<PrepRange> rs;
+    int rc = scan_ranges(c, s, rs);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    for (int64_t off = 0; off < c->M; off += pl.range)
-        if ((rc = launch_range(c, pl, off, std::min(pl.range, c->M - off)))) return rc;
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(hipEventRecord(s->ev0, c->stream));
+    for (const PrepRange &r : rs)
+        if ((rc = launch_range(c, s, s->plan, r.off, r.cnt, s->plan.mode == 4 ? &r : nullptr))) return rc;
+    HIP_TRY(hipEventRecord(s->ev1, c->stream));
+    s->timed = true;
+    return BMX_OK;
+}
+
+/* What the scan of the selected slot will launch (valid once the test sites are set): group size J (0: one test site per
+ * wave), 1 if the R slice is read from LDS, the inner-loop mode (4: prepared pipeline, 0..3: round-2 grouped forms, -1:
+ * per-site kernel), and the bytes of the prepared stream of all test sites (0 otherwise).  Any pointer may be NULL. */
+int bmx_ctx_plan(bmx_ctx *c, int32_t *J, int32_t *use_lds, int32_t *mode, int64_t *stream_bytes) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    ChromSlot *s = c->cur;
+    if (!c->has_model || !s->has_sites || !s->has_tests) return fail(BMX_E_STATE, "model, sites and tests must be set before the plan exists");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_plan(c, s);
+    if (rc) return rc;
+    if (J) *J = s->plan.J;
+    if (use_lds) *use_lds = s->plan.use_lds ? 1 : 0;
+    if (mode) *mode = s->plan.mode;
+    if (stream_bytes) {
+        int64_t u = 0;
+        if (s->plan.mode == 4) for (const PrepRange &r : s->ranges) u += r.units;
+        *stream_bytes = u * (int64_t)sizeof(ScratchEnt);
+    }
     return BMX_OK;
 }
 
@@ -2141,55 +3251,84 @@ int bmx_ctx_sync(bmx_ctx *c) {
         if (tot > 0) for (int k = 0; k < 12; k++) fprintf(stderr, "[bmx prof] %-36s %5.1f %%\n", nm[k], 100.0 * (double)h[k] / tot);
     }
 #endif
-    return BMX_OK;
+    return check_status(c);
+}
+
+/* The records of every slot that holds scan results, in slot order, back to back: the whole genome's results with one
+ * call (and, on a device buffer, what ONE gather then moves to the writing rank).  dst: room for `cap` records, in host
+ * memory (dst_on_device = 0) or device memory of this context's GPU (1); n_out: records written.  Blocks until done. */
+int bmx_ctx_pack_records(bmx_ctx *c, void *dst, int64_t cap, int32_t dst_on_device, int64_t *n_out) {
+    if (!c || (!dst && cap > 0)) return fail(BMX_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int64_t n = 0;
+    for (ChromSlot *s : c->slots)
+        if (s && s->has_tests && s->timed) n += s->M;
+    if (n_out) *n_out = n;
+    if (n > cap) return fail(BMX_E_INVALID, "pack_records: destination too small");
+    int64_t at = 0;
+    for (ChromSlot *s : c->slots) {
+        if (!s || !s->has_tests || !s->timed) continue;
+        HIP_TRY(hipMemcpyAsync((bmx_record *)dst + at, s->rec.p, (size_t)s->M * sizeof(bmx_record),
+                               dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+        at += s->M;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return check_status(c);
 }
 
 int bmx_ctx_last_scan_ms(bmx_ctx *c, double *ms) {
     if (!c || !ms) return fail(BMX_E_INVALID, "NULL argument");
-    if (!c->timed) return fail(BMX_E_STATE, "no scan has been launched");
-    HIP_TRY(hipEventSynchronize(c->ev1));
+    ChromSlot *s = c->cur;
+    if (!s->timed) return fail(BMX_E_STATE, "no scan has been launched");
+    HIP_TRY(hipEventSynchronize(s->ev1));
     float f = 0;
-    HIP_TRY(hipEventElapsedTime(&f, c->ev0, c->ev1));
+    HIP_TRY(hipEventElapsedTime(&f, s->ev0, s->ev1));
     *ms = f;
     return BMX_OK;
 }
 
 int bmx_ctx_result_ptrs(bmx_ctx *c, void **d_clr, void **d_lin, void **d_nsites) {
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
-    if (!c->has_tests || !c->timed) return fail(BMX_E_STATE, "no scan results: call bmx_ctx_scan after bmx_ctx_set_tests");
-    if (d_clr) *d_clr = c->clr.p;
-    if (d_lin) *d_lin = c->lin.p;
-    if (d_nsites) *d_nsites = c->nsites.p;
+    ChromSlot *s = c->cur;
+    if (!s->has_tests || !s->timed) return fail(BMX_E_STATE, "no scan results: call bmx_ctx_scan after bmx_ctx_set_tests");
+    if (d_clr) *d_clr = s->clr.p;
+    if (d_lin) *d_lin = s->lin.p;
+    if (d_nsites) *d_nsites = s->nsites.p;
     return BMX_OK;
 }
 
 int bmx_ctx_records(bmx_ctx *c, void **d_rec) {
     if (!c || !d_rec) return fail(BMX_E_INVALID, "NULL argument");
-    if (!c->has_tests || !c->timed) return fail(BMX_E_STATE, "no scan results: call bmx_ctx_scan after bmx_ctx_set_tests");
-    *d_rec = c->rec.p;
+    ChromSlot *s = c->cur;
+    if (!s->has_tests || !s->timed) return fail(BMX_E_STATE, "no scan results: call bmx_ctx_scan after bmx_ctx_set_tests");
+    *d_rec = s->rec.p;
     return BMX_OK;
 }
 
 int bmx_ctx_fetch_records(bmx_ctx *c, bmx_record *rec) {
     if (!c || !rec) return fail(BMX_E_INVALID, "NULL argument");
-    if (!c->has_tests || !c->timed) return fail(BMX_E_STATE, "no scan results to fetch");
+    ChromSlot *s = c->cur;
+    if (!s->has_tests || !s->timed) return fail(BMX_E_STATE, "no scan results to fetch");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(rec, c->rec.p, (size_t)c->M * sizeof(bmx_record), hipMemcpyDeviceToHost));
+    if (int st = check_status(c)) return st;
+    HIP_TRY(hipMemcpy(rec, s->rec.p, (size_t)s->M * sizeof(bmx_record), hipMemcpyDeviceToHost));
     return BMX_OK;
 }
 
 int bmx_ctx_fetch(bmx_ctx *c, double *clr, int32_t *ix, int32_t *ia, int32_t *iA, int32_t *nsites) {
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
-    if (!c->has_tests || !c->timed) return fail(BMX_E_STATE, "no scan results to fetch");
+    ChromSlot *s = c->cur;
+    if (!s->has_tests || !s->timed) return fail(BMX_E_STATE, "no scan results to fetch");
     HIP_TRY(hipSetDevice(c->device));
-    std::vector<int32_t> lin((size_t)c->M);
+    std::vector<int32_t> lin((size_t)s->M);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (clr) HIP_TRY(hipMemcpy(clr, c->clr.p, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost));
-    if (nsites) HIP_TRY(hipMemcpy(nsites, c->nsites.p, (size_t)c->M * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(lin.data(), c->lin.p, (size_t)c->M * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (int st = check_status(c)) return st;
+    if (clr) HIP_TRY(hipMemcpy(clr, s->clr.p, (size_t)s->M * sizeof(double), hipMemcpyDeviceToHost));
+    if (nsites) HIP_TRY(hipMemcpy(nsites, s->nsites.p, (size_t)s->M * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lin.data(), s->lin.p, (size_t)s->M * sizeof(int32_t), hipMemcpyDeviceToHost));
     const int32_t npairs = c->npairs, nab = c->nab;
-    parallel_ranges(c->M, 1 << 18, [&](int, int64_t b, int64_t e) {
+    parallel_ranges(s->M, 1 << 18, [&](int, int64_t b, int64_t e) {
         for (int64_t t = b; t < e; t++) {
             const int32_t L = lin[(size_t)t];
             int32_t a = -1, bb = -1, d = -1;
@@ -2220,12 +3359,13 @@ int bmx_ctx_fetch_lut(bmx_ctx *c, double *psel_out, double *R_out) {
 
 int bmx_ctx_surface(bmx_ctx *c, double test_gen, int64_t win_lo, int64_t win_hi, double *T_out, int32_t *nsites_out) {
     if (!c || !T_out) return fail(BMX_E_INVALID, "NULL argument");
-    if (!c->has_model || !c->has_sites) return fail(BMX_E_STATE, "model and sites must be set before surface");
+    ChromSlot *s = c->cur;
+    if (!c->has_model || !s->has_sites) return fail(BMX_E_STATE, "model and sites must be set before surface");
     HIP_TRY(hipSetDevice(c->device));
     SurfParams S;
-    S.genpos = c->genpos.p; S.row = RowArray{c->wide_rows ? nullptr : c->row16.p, c->wide_rows ? c->row32.p : nullptr}; S.N = c->N; S.Rt = c->d_Rt; S.NP = c->NP; S.npairs = c->npairs;
+    S.genpos = s->genpos.p; S.row = RowArray{s->wide_rows ? nullptr : s->row16.p, s->wide_rows ? s->row32.p : nullptr}; S.N = s->N; S.Rt = c->d_Rt; S.NP = c->NP; S.npairs = c->npairs;
     S.nslices = c->nslices; S.A = c->d_A; S.nA = c->nA; S.tg = test_gen;
-    S.lo = std::max<int64_t>(win_lo, 0); S.hi = std::min<int64_t>(win_hi, c->N - 1); S.zcut = c->zcut;
+    S.lo = std::max<int64_t>(win_lo, 0); S.hi = std::min<int64_t>(win_hi, s->N - 1); S.zcut = c->zcut;
     HIP_TRY(c->surf_T.ensure((size_t)c->nA * c->npairs));
     HIP_TRY(c->surf_ns.ensure((size_t)c->nA));
     S.T = c->surf_T.p; S.ns = c->surf_ns.p;
@@ -2250,15 +3390,37 @@ int bmx_ctx_surface(bmx_ctx *c, double test_gen, int64_t win_lo, int64_t win_hi,
 extern "C" int bmx_ctx_scan_write(bmx_ctx *c, const char *path, const int64_t *phys, const double *gen,
                                   const char *xs, int nx, const char *abs_, int nab, const char *As, int nA, int64_t chunk) {
     if (!c || !path || !phys || !gen || !xs || !abs_ || !As) return fail(BMX_E_INVALID, "NULL argument");
-    if (!c->has_model || !c->has_sites || !c->has_tests) return fail(BMX_E_STATE, "model, sites and tests must be set before scan");
+    ChromSlot *s = c->cur;
+    if (!c->has_model || !s->has_sites || !s->has_tests) return fail(BMX_E_STATE, "model, sites and tests must be set before scan");
     if (nx != c->nx || nab != c->nab || nA != c->nA) return fail(BMX_E_INVALID, "printed grids do not match the model's grids");
     HIP_TRY(hipSetDevice(c->device));
-    ScanPlan pl;
-    int rc = plan_scan(c, pl);
+    std::vector<PrepRange> rs;
+    int rc = scan_ranges(c, s, rs);
     if (rc) return rc;
-    if (chunk <= 0) chunk = 65536;
-    chunk = std::min<int64_t>(std::max<int64_t>(chunk / pl.spb, 1) * pl.spb, pl.range);
-    const size_t slot_bytes = (size_t)chunk * 16;
+    ScanPlan &pl = s->plan;
+    // chunks: the prepared pipeline's launch ranges as they are (their blobs were sized per range); otherwise `chunk` test
+    // sites at a time (0: 65536; whole workgroups, which keeps every result bit-identical to bmx_ctx_scan)
+    std::vector<PrepRange> chunks;
+    if (pl.mode == 4) {
+        // a prepared range is cut further into chunks of whole workgroups: each chunk's groups are a sub-range of the
+        // range's blobs (same arena, same prefix base), so nothing has to be re-planned
+        if (chunk <= 0) chunk = 65536;
+        chunk = std::max<int64_t>(chunk / pl.spb, 1) * pl.spb;
+        for (const PrepRange &r : rs)
+            for (int64_t o = 0; o < r.cnt; o += chunk) {
+                PrepRange q = r;
+                q.off = r.off + o;
+                q.cnt = std::min(chunk, r.cnt - o);
+                chunks.push_back(q);
+            }
+    } else {
+        if (chunk <= 0) chunk = 65536;
+        chunk = std::min<int64_t>(std::max<int64_t>(chunk / pl.spb, 1) * pl.spb, pl.range);
+        for (int64_t off = 0; off < s->M; off += chunk) chunks.push_back(PrepRange{off, std::min(chunk, s->M - off), 0, 0, 0, 0});
+    }
+    int64_t chunk_max = 1;
+    for (const PrepRange &q : chunks) chunk_max = std::max(chunk_max, q.cnt);
+    const size_t slot_bytes = (size_t)chunk_max * 16;
     if (c->h_stage_cap < slot_bytes) {
         for (int k = 0; k < 2; k++) {
             if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
@@ -2280,6 +3442,7 @@ extern "C" int bmx_ctx_scan_write(bmx_ctx *c, const char *path, const int64_t *p
     std::deque<Job> jobs;
     bool slot_free[2] = {true, true}, done = false;
     int werr = 0;                  // 1: event wait failed, 2: formatting/writing failed
+    std::string wmsg;              // the writer thread's own message (bmx_last_error is thread-local)
     std::thread writer([&]() {
         (void)hipSetDevice(c->device);
         for (;;) {
@@ -2292,22 +3455,27 @@ extern "C" int bmx_ctx_scan_write(bmx_ctx *c, const char *path, const int64_t *p
                 jobs.pop_front();
             }
             int e = 0;
+            std::string msg;
             if (hipEventSynchronize(c->ev_copied[j.slot]) != hipSuccess) e = 1;
             if (!e && !werr) {
                 const char *base = (const char *)c->h_stage[j.slot];
                 const double *hclr = (const double *)base;
-                const int32_t *hlin = (const int32_t *)(base + (size_t)chunk * 8);
-                const int32_t *hns = (const int32_t *)(base + (size_t)chunk * 12);
-                if (bmx_write_chunk_(f, tabs, j.cnt, phys + j.off, gen + j.off, hclr, nullptr, nullptr, nullptr, hlin, hns)) e = 2;
+                const int32_t *hlin = (const int32_t *)(base + (size_t)chunk_max * 8);
+                const int32_t *hns = (const int32_t *)(base + (size_t)chunk_max * 12);
+                if (bmx_write_chunk_(f, tabs, j.cnt, phys + j.off, gen + j.off, hclr, nullptr, nullptr, nullptr, hlin, hns)) {
+                    e = 2;
+                    msg = bmx_last_error();       // set on THIS thread by bmx_write_chunk_
+                }
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
-                if (e && !werr) werr = e;
+                if (e && !werr) { werr = e; wmsg = msg; }
                 slot_free[j.slot] = true;
             }
             cv.notify_all();
         }
     });
+    bool all_launched = false;
     auto finish = [&](int code, const std::string &msg) {
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -2319,45 +3487,53 @@ extern "C" int bmx_ctx_scan_write(bmx_ctx *c, const char *path, const int64_t *p
         (void)hipStreamSynchronize(c->copy_stream);
         const bool wfail = fclose(f) != 0;
         bmx_row_tables_free_(tabs);
+        s->timed = all_launched && !werr && !code;     // results are fetchable only when every chunk was scanned
         if (code) return fail(code, msg);
         if (werr == 1) return fail(BMX_E_HIP, "streaming writer: waiting for a result copy failed");
-        if (werr == 2) return fail(BMX_E_INVALID, std::string("streaming writer: ") + bmx_last_error());
+        if (werr == 2) return fail(BMX_E_INVALID, std::string("streaming writer: ") + wmsg);
         if (wfail) return fail(BMX_E_INVALID, "write failed");
-        return (int)BMX_OK;
+        return check_status(c);
     };
 #define STREAM_TRY(expr)                                                                                  \
     do {                                                                                                  \
         hipError_t e_ = (expr);                                                                           \
         if (e_ != hipSuccess) return finish(BMX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
-    STREAM_TRY(hipEventRecord(c->ev0, c->stream));
-    int k = 0;
-    for (int64_t off = 0; off < c->M; off += chunk, ++k) {
-        const int64_t cnt = std::min(chunk, c->M - off);
-        const int slot = k & 1;
+    STREAM_TRY(hipEventRecord(s->ev0, c->stream));
+    size_t k = 0;
+    bool stopped = false;
+    for (; k < chunks.size(); ++k) {
+        const PrepRange &q = chunks[k];
+        const int slot = (int)(k & 1);
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return slot_free[slot]; });
-            if (werr) break;
+            if (werr) { stopped = true; break; }
             slot_free[slot] = false;
         }
-        if ((rc = launch_range(c, pl, off, cnt))) return finish(rc, g_err);
+        if (pl.mode == 4) {
+            // the chunk's groups within its range: fill + consume exactly those
+            PrepRange sub = q;
+            sub.g0 = q.off / pl.J;
+            sub.ng = (q.cnt + pl.J - 1) / pl.J;
+            if ((rc = launch_range(c, s, pl, q.off, q.cnt, &sub))) return finish(rc, g_err);
+        } else if ((rc = launch_range(c, s, pl, q.off, q.cnt, nullptr))) return finish(rc, g_err);
         STREAM_TRY(hipEventRecord(c->ev_done[slot], c->stream));
         STREAM_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_done[slot], 0));
         char *base = (char *)c->h_stage[slot];
-        STREAM_TRY(hipMemcpyAsync(base, c->clr.p + off, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->copy_stream));
-        STREAM_TRY(hipMemcpyAsync(base + (size_t)chunk * 8, c->lin.p + off, (size_t)cnt * 4, hipMemcpyDeviceToHost, c->copy_stream));
-        STREAM_TRY(hipMemcpyAsync(base + (size_t)chunk * 12, c->nsites.p + off, (size_t)cnt * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        STREAM_TRY(hipMemcpyAsync(base, s->clr.p + q.off, (size_t)q.cnt * 8, hipMemcpyDeviceToHost, c->copy_stream));
+        STREAM_TRY(hipMemcpyAsync(base + (size_t)chunk_max * 8, s->lin.p + q.off, (size_t)q.cnt * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        STREAM_TRY(hipMemcpyAsync(base + (size_t)chunk_max * 12, s->nsites.p + q.off, (size_t)q.cnt * 4, hipMemcpyDeviceToHost, c->copy_stream));
         STREAM_TRY(hipEventRecord(c->ev_copied[slot], c->copy_stream));
         {
             std::lock_guard<std::mutex> lk(mu);
-            jobs.push_back(Job{slot, off, cnt});
+            jobs.push_back(Job{slot, q.off, q.cnt});
         }
         cv.notify_all();
     }
-    STREAM_TRY(hipEventRecord(c->ev1, c->stream));
+    STREAM_TRY(hipEventRecord(s->ev1, c->stream));
 #undef STREAM_TRY
-    c->timed = true;
+    all_launched = !stopped;
     return finish(BMX_OK, "");
 }
 

@@ -73,6 +73,8 @@ class Context:
         _lib.check(self._L.bmx_ctx_create(C.byref(self._h), int(device)))
         self.device = int(device)
         self.M = 0
+        self.slot = 0
+        self._slot_M = {}
         self._keep = []
 
     def close(self):
@@ -89,6 +91,8 @@ class Context:
     def set_model(self, model, As):
         A = _lib.f64(As)
         self.model, self.nA = model, len(A)
+        self._slot_M = {}
+        self.M = 0
         _lib.check(self._L.bmx_ctx_set_model(self._h, C.byref(model.c), _lib.as_dp(A), len(A)))
 
     def set_sites(self, genpos, rows):
@@ -99,10 +103,44 @@ class Context:
     def set_tests(self, test_gen, win_lo, win_hi):
         t, lo, hi = _lib.f64(test_gen), _lib.i64(win_lo), _lib.i64(win_hi)
         self.M = len(t)
+        self._slot_M[self.slot] = self.M
         _lib.check(self._L.bmx_ctx_set_tests(self._h, len(t), _lib.as_dp(t), _lib.as_lp(lo), _lib.as_lp(hi)))
 
     def set_variant(self, v):
         _lib.check(self._L.bmx_ctx_set_variant(self._h, int(v)))
+
+    def select_slot(self, k):
+        """Chromosome slot k of this context (created on first use): its own site arrays, test sites and results,
+        the context's one model.  set_sites / set_tests / scan / fetch* act on the selected slot."""
+        _lib.check(self._L.bmx_ctx_select_slot(self._h, int(k)))
+        self.slot = int(k)
+        self.M = self._slot_M.get(self.slot, 0)
+
+    def plan(self):
+        """{'J', 'use_lds', 'mode', 'stream_bytes', 'kernel'} of the selected slot's scan (bmx_ctx_plan)."""
+        J, ul, mode = C.c_int32(), C.c_int32(), C.c_int32()
+        sb = C.c_int64()
+        _lib.check(self._L.bmx_ctx_plan(self._h, C.byref(J), C.byref(ul), C.byref(mode), C.byref(sb)))
+        lds = 'true' if ul.value else 'false'
+        if mode.value == 4:
+            name = 'clr_scan_prepared_kernel<%d,%s>' % (J.value, lds)
+        elif mode.value >= 0:
+            name = 'clr_scan_grouped_kernel<%d,%s,%d>' % (J.value, lds, mode.value)
+        else:
+            name = 'clr_scan_kernel<%s>' % lds
+        return {'J': J.value, 'use_lds': bool(ul.value), 'mode': mode.value, 'stream_bytes': sb.value, 'kernel': name}
+
+    def pack_records(self, out=None, device_ptr=None, cap=None):
+        """Records of every slot with results, slot order.  Host: returns a RECORD array.  device_ptr/cap: packs into
+        that device buffer (room for cap records) and returns the count."""
+        n = C.c_int64()
+        if device_ptr is not None:
+            _lib.check(self._L.bmx_ctx_pack_records(self._h, C.c_void_p(int(device_ptr)), int(cap), 1, C.byref(n)))
+            return n.value
+        total = sum(self._slot_M.values())
+        rec = out if out is not None else np.empty(total, dtype=_lib.RECORD_DTYPE)
+        _lib.check(self._L.bmx_ctx_pack_records(self._h, rec.ctypes.data_as(C.c_void_p), len(rec), 0, C.byref(n)))
+        return rec[:n.value]
 
     def scan(self):
         _lib.check(self._L.bmx_ctx_scan(self._h))

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define BMX_ABI_VERSION_MAJOR 1
-#define BMX_ABI_VERSION_MINOR 1
+#define BMX_ABI_VERSION_MINOR 2
 
 enum {
     BMX_OK = 0,
@@ -113,14 +113,23 @@ int bmx_scan(const bmx_model *m, const double *A, int32_t nA, int64_t N, const d
 
 /* ---- resident-context entry points ------------------------------------------------- */
 /* Same computation split so that inputs stay resident in HBM across scans (one context per
- * process per GPU; the multi-GPU driver shards test sites across processes). */
+ * process per GPU; the multi-GPU driver shards test sites across processes).
+ * A context holds ONE model (selection table + A grid) and any number of chromosome SLOTS, each with its own site
+ * arrays, test sites and results: the reference runs one input file per process (BalLeRMix+_v1.py:777-799); a
+ * whole-genome run here selects slot k, sets chromosome k's sites and test sites, and scans the slots back to back on
+ * the context's stream with the table built once.  Slot 0 exists from creation and is selected; set_sites, set_tests,
+ * scan, fetch*, records, result_ptrs, last_scan_ms, scan_write, surface and plan act on the selected slot. */
 typedef struct bmx_ctx bmx_ctx;
 
 int bmx_ctx_create(bmx_ctx **out, int device);
 void bmx_ctx_destroy(bmx_ctx *c);
 /* Build the selection table on the device (K1) and keep it resident.  Call order: set_model, then
- * set_sites, then set_tests; a new model discards the site and test arrays set under the old one (their
- * row indices belong to it), and new sites discard the test sites (located in the old array). */
+ * set_sites, then set_tests; a new model discards the site and test arrays of EVERY slot (their
+ * row indices belong to the old one), and new sites discard the slot's test sites (located in the old array).
+ * The table's bit pattern follows the HOST's libm: scipy evaluates lgam's log with glibc's log, which is not correctly
+ * rounded on ~0.015 % of arguments, so set_model evaluates this host's log on every argument the table build will use
+ * and ships the exceptions to the device (bmx_math.h LogPatch).  The device table is therefore a function of the
+ * model AND of the host library -- by design: it reproduces what scipy computes on this box. */
 int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t nA);
 /* Copy the site arrays of one chromosome to the device (and rank its rows by frequency for the scan
  * kernel's far-field moments). */
@@ -164,6 +173,19 @@ int bmx_ctx_surface(bmx_ctx *c, double test_gen, int64_t win_lo, int64_t win_hi,
                     int32_t *nsites_out);
 /* Choose the scan kernel variant (0 = default). For A/B measurements only. */
 int bmx_ctx_set_variant(bmx_ctx *c, int variant);
+/* Select (creating it on first use) chromosome slot `slot`, 0 <= slot < 4096. */
+int bmx_ctx_select_slot(bmx_ctx *c, int32_t slot);
+/* Number of slot indices in use (highest selected slot + 1). */
+int bmx_ctx_slot_count(bmx_ctx *c);
+/* The records of every slot that holds scan results, in slot order, back to back: the whole genome's rows with one
+ * call -- to host memory (dst_on_device = 0), or to device memory of this context's GPU (1), where ONE gather then
+ * moves them to the writing rank.  dst: room for `cap` records; *n_out (may be NULL): records written.  Blocks. */
+int bmx_ctx_pack_records(bmx_ctx *c, void *dst, int64_t cap, int32_t dst_on_device, int64_t *n_out);
+/* What the scan of the selected slot launches (valid once its test sites are set): *J = test sites per wave-group (0: one
+ * test site per wave), *use_lds = 1 if the R slice is read from LDS, *mode = 4 prepared pipeline (prep_kernel +
+ * clr_scan_prepared_kernel), 0..3 the round-2 grouped forms, -1 the per-site kernel; *stream_bytes = bytes of the prepared
+ * per-group streams of all test sites (0 otherwise).  Any pointer may be NULL. */
+int bmx_ctx_plan(bmx_ctx *c, int32_t *J, int32_t *use_lds, int32_t *mode, int64_t *stream_bytes);
 
 /* ---- input ingest (host only) ------------------------------ */
 /* Native reader of the 4-column input that InputData.readCounts / readPolyCalls parse line by
