@@ -76,6 +76,8 @@ PROTOTYPES = {
     'bmx_input_parse': (C.c_int, [C.c_char_p, C.c_int64, C.c_int, _lp, _dp, _lp, _lp]),
     'bmx_write_rows': (C.c_int, [C.c_char_p, C.c_int64, _lp, _dp, _dp, _ip, _ip, _ip, _ip, C.c_char_p, C.c_int,
                                  C.c_char_p, C.c_int, C.c_char_p, C.c_int]),
+    'bmx_write_records': (C.c_int, [C.c_char_p, C.c_int64, _lp, _dp, C.POINTER(_vp), C.c_int32, C.c_int64, C.c_char_p, C.c_int,
+                                    C.c_char_p, C.c_int, C.c_char_p, C.c_int]),
     'bmx_py_repr': (C.c_int, [C.c_double, C.c_char_p]),
 }
 
@@ -166,3 +168,15 @@ def write_rows(path, phys, gen, clr, ix, ia, iA, ns, xs, abs_, As):
     pack = lambda v: b'\0'.join(s.encode() for s in v) + b'\0'
     check(L.bmx_write_rows(path.encode(), len(phys), as_lp(phys), as_dp(gen), as_dp(clr), as_ip(ix), as_ip(ia),
                            as_ip(iA), as_ip(ns), pack(xs), len(xs), pack(abs_), len(abs_), pack(As), len(As)))
+
+
+def write_records(path, phys, gen, per_rank, block, xs, abs_, As):
+    """Append the rows of a sharded run from its gathered 16-byte records: per_rank[r] = RECORD array of rank r (its test
+    sites in its own order; blocks of `block` test sites dealt round-robin).  One rank: per_rank = [records in order]."""
+    L = lib()
+    phys, gen = i64(phys), f64(gen)
+    keep = [np.ascontiguousarray(a, dtype=RECORD_DTYPE) for a in per_rank]
+    ptrs = (_vp * len(keep))(*[a.ctypes.data_as(_vp) for a in keep])
+    pack = lambda v: b'\0'.join(s.encode() for s in v) + b'\0'
+    check(L.bmx_write_records(path.encode(), len(phys), as_lp(phys), as_dp(gen), ptrs, len(keep), int(block), pack(xs), len(xs),
+                              pack(abs_), len(abs_), pack(As), len(As)))

@@ -349,6 +349,39 @@ extern "C" int bmx_write_chunk_(FILE *f, const bmx_row_tables_ *t, int64_t n, co
 
 extern "C" {
 
+// Rows from 16-byte records as a sharded run gathers them: per_rank[r] = the records of rank r's test sites in its own
+// order, test sites dealt to the ranks in blocks of `block` round-robin (distributed.assign).  world = 1: the records in order.
+int bmx_write_records(const char *path, int64_t M, const int64_t *phys, const double *gen, const bmx_record *const *per_rank,
+                      int32_t world, int64_t block, const char *xs, int nx, const char *abs_, int nab, const char *As, int nA) {
+    if (!path || (M > 0 && (!phys || !gen || !per_rank)) || world < 1 || block < 1 || !xs || !abs_ || !As) {
+        bmx_set_error_("bad argument");
+        return BMX_E_INVALID;
+    }
+    for (int r = 0; r < world; ++r) {
+        const int64_t nblk = (M + block - 1) / block;
+        if (!per_rank[r] && nblk > r) { bmx_set_error_("bad argument: a rank's records are missing"); return BMX_E_INVALID; }
+    }
+    FILE *f = fopen(path, "a");
+    if (!f) { bmx_set_error_((std::string("cannot open ") + path + ": " + strerror(errno)).c_str()); return BMX_E_INVALID; }
+    bmx_row_tables_ *t = bmx_row_tables_new_(xs, nx, abs_, nab, As, nA);
+    int rc = BMX_OK;
+    constexpr int64_t CH = 1 << 18;                         // bounded staging and formatting buffers
+    std::vector<double> clr((size_t)std::min(CH, std::max<int64_t>(M, 1)));
+    std::vector<int32_t> lin(clr.size()), ns(clr.size());
+    for (int64_t off = 0; off < M && !rc; off += CH) {
+        const int64_t cnt = std::min<int64_t>(CH, M - off);
+        for (int64_t i = 0; i < cnt; ++i) {
+            const int64_t tt = off + i, b = tt / block;
+            const bmx_record &q = per_rank[b % world][(b / world) * block + tt % block];
+            clr[(size_t)i] = q.clr; lin[(size_t)i] = q.lin; ns[(size_t)i] = q.nsites;
+        }
+        rc = bmx_write_chunk_(f, t, cnt, phys + off, gen + off, clr.data(), nullptr, nullptr, nullptr, lin.data(), ns.data());
+    }
+    bmx_row_tables_free_(t);
+    if (fclose(f) != 0 && !rc) { bmx_set_error_("write failed"); rc = BMX_E_INVALID; }
+    return rc;
+}
+
 // repr(v) into buf (>= 32 bytes); returns its length.  Exposed for the tests.
 int bmx_py_repr(double v, char *buf) {
     char *e = py_repr(buf, v);

@@ -205,6 +205,12 @@ int bmx_input_parse(const char *path, int64_t N, int pos_col, int64_t *phys, dou
 int bmx_write_rows(const char *path, int64_t M, const int64_t *phys, const double *gen, const double *clr,
                    const int32_t *ix, const int32_t *ia, const int32_t *iA, const int32_t *nsites,
                    const char *xs, int nx, const char *abs_, int nab, const char *As, int nA);
+/* The same rows from 16-byte records as a sharded run gathers them on the writing rank: per_rank[r] = the records of rank
+ * r's test sites in its own order, test sites dealt to the `world` ranks in blocks of `block` consecutive test sites
+ * round-robin.  world = 1 (block: any value >= 1): M records in output order.  Appends to `path`. */
+int bmx_write_records(const char *path, int64_t M, const int64_t *phys, const double *gen,
+                      const bmx_record *const *per_rank, int32_t world, int64_t block,
+                      const char *xs, int nx, const char *abs_, int nab, const char *As, int nA);
 /* repr(v) as Python prints it, into buf (>= 32 bytes); returns the length. */
 int bmx_py_repr(double v, char *buf);
 
