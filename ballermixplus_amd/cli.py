@@ -4,6 +4,12 @@ InputData -> NeutralSFS -> get_neut_probs -> Grids -> NormalizedBetaBinom -> Sca
 
 Additions (do not change any reference command line):
   --device K        GPU index for a single-process run (default 0)
+  -i a.txt,b.txt,... | --inputs LIST.txt     several input files (a whole genome, one file per chromosome) in ONE process
+                    on one scan context: the selection table is built once (and rebuilt only when a file's sample sizes
+                    or minCount differ), the next file is read while the current one is scanned, and -o names a directory
+                    (created; outputs are <dir>/<input basename>.out.txt) or a pattern containing {} (replaced by the
+                    input's basename without extension).  The reference handles one file per process
+                    (BalLeRMix+_v1.py:777-799); looping it pays process start, HIP start-up and the table once per file.
 Multi-GPU: launch under `python -m torch.distributed.run --nproc-per-node N -m ballermixplus_amd.cli ...`;
 test sites are sharded over the ranks (rank r computes on GPU LOCAL_RANK), rank 0 gathers the 16-byte records
 (one RCCL gather) and writes the output file.  BMX_DIST_BACKEND=gloo BMX_SINGLE_DEVICE=1 lets several ranks
@@ -19,7 +25,7 @@ def build_parser():
     """Flags, destinations, types and defaults are the reference's (v1:718-753): its command lines run unchanged.
     The help texts are this build's own wording."""
     parser = argparse.ArgumentParser(description='BalLeRMix+ B-statistic scan on AMD Instinct MI355X (libbmxscan).')
-    parser.add_argument('-i', '--input', dest='infile', required=True,
+    parser.add_argument('-i', '--input', dest='infile', required=False, default=None,
                         help='input file: header line, then tab-separated physPos, genPos, derived (or minor) allele count x, sample size n')
     parser.add_argument('-o', '--output', dest='outfile', help='output file (7 tab-separated columns, one row per test site)')
     parser.add_argument('--spect', dest='spectfile', required=True,
@@ -60,6 +66,9 @@ def build_parser():
     parser.add_argument('--rangeA', dest='seqA', help='linkage parameter grid as <Amin>,<Amax>,<Astep> (no spaces)')
     parser.add_argument('--listA', dest='listA', help='linkage parameter grid as a comma-separated list (no spaces)')
     # additions
+    parser.add_argument('--inputs', dest='inputs', default=None,
+                        help='MI355X build only: a text file naming several input files, one per line (whole genome in one process); '
+                             'equivalent to -i a.txt,b.txt,...; -o is then a directory or a pattern containing {}')
     parser.add_argument('--device', dest='device', type=int, default=None,
                         help='GPU index for a single-process run (MI355X build only; not allowed under torch.distributed.run, where every rank uses GPU LOCAL_RANK)')
     return parser
@@ -76,6 +85,16 @@ def main(argv=None):
         parser.print_help()
         sys.exit()
     opt = parser.parse_args(argv)
+    if opt.infile is None and opt.inputs is None:
+        parser.error('the following arguments are required: -i/--input')
+    files = None
+    if opt.inputs is not None:
+        with open(opt.inputs) as f:
+            files = [l.strip() for l in f if l.strip() and not l.startswith('#')]
+    elif ',' in opt.infile and not os.path.exists(opt.infile):
+        files = [p for p in opt.infile.split(',') if p]
+    if files is not None and not (opt.getSpec or opt.getConfig):
+        return main_many(opt, files, stamp)
 
     from . import helpers
     if opt.getSpec:
@@ -148,6 +167,86 @@ def main(argv=None):
     stamp('table, scan, output')
     world.finish()
     say(f'\n{datetime.now()}. Pipeline finished.')
+
+
+def output_name(outspec, infile):
+    """-o of the multi-file form: a pattern containing {} (the input's basename without extension goes there) or a directory."""
+    base = os.path.basename(infile)
+    if '{}' in outspec:
+        return outspec.replace('{}', os.path.splitext(base)[0])
+    return os.path.join(outspec, base + '.out.txt')
+
+
+def main_many(opt, files, stamp=lambda what: None):
+    """Several input files through the reference's stages (InputData -> NeutralSFS.get_neut_probs -> NormalizedBetaBinom ->
+    Scan, BalLeRMix+_v1.py:777-799) in one process on one scan context: file i + 1 is read and given its neutral
+    probabilities on a helper thread while file i is scanned and written (the native calls release the GIL)."""
+    import threading
+    from . import distributed, engine
+    from .hostmodel import Grids, InputData, NeutralSFS
+    from .scan import Scan
+    if not files:
+        print('No input files given.')
+        sys.exit(1)
+    if not opt.outfile:
+        print('Several input files need -o <directory> or -o <pattern with {}>.')
+        sys.exit(1)
+    world = distributed.World.from_env(backend=os.environ.get('BMX_DIST_BACKEND'))
+    if world.distributed and opt.device is not None:
+        print('--device cannot be combined with a multi-process launch: each rank uses GPU LOCAL_RANK.')
+        sys.exit(1)
+    device = opt.device if opt.device is not None else world.device_index
+    verbose = world.rank == 0
+
+    def say(*a):
+        if verbose:
+            print(*a)
+
+    outs = [output_name(opt.outfile, f) for f in files]
+    if len(set(outs)) != len(outs):
+        print('Two input files map to the same output name; give -o a pattern with {} or distinct basenames.')
+        sys.exit(1)
+    if world.rank == 0 and '{}' not in opt.outfile:
+        os.makedirs(opt.outfile, exist_ok=True)
+    grid = Grids(opt.x, opt.abeta, opt.bal, opt.pos, opt.seqA, opt.listA)
+    say('\nOptimizing over x= ' + ', '.join(['%g' % (x) for x in grid.x]))
+    say('\n \t alpha= ' + ', '.join([str(a) for a in grid.abeta]))
+    say('\n \t A= ' + ', '.join([str(A) for A in grid.A]))
+    block = int(os.environ['BMX_SHARD_BLOCK']) if os.environ.get('BMX_SHARD_BLOCK') else None
+    runner = world.sharded_runner(block=block) if world.distributed else None
+    nxt = {}
+
+    def host_stage(i):
+        try:
+            data = InputData(files[i], opt.nofreq, opt.MAF, opt.nosub, opt.minCount, phys=opt.phys, Rrate=opt.Rrate)
+            neut = NeutralSFS(opt.spectfile, opt.nofreq, opt.MAF, opt.nosub)
+            neut.get_neut_probs(data)
+            nxt[i] = (data, neut)
+        except BaseException as e:          # incl. the reference-style sys.exit() of the readers: re-raised on the main thread
+            nxt[i] = e
+
+    th = threading.Thread(target=host_stage, args=(0,))
+    th.start()
+    ctx = None
+    tables = 0
+    for i, (infile, outfile) in enumerate(zip(files, outs)):
+        th.join()
+        got = nxt.pop(i)
+        if isinstance(got, BaseException):
+            raise got
+        data, neut = got
+        if i + 1 < len(files):
+            th = threading.Thread(target=host_stage, args=(i + 1,))
+            th.start()
+        say(f"\n{datetime.now()}. {infile} -> {outfile}")
+        sel = engine.NormalizedBetaBinom(data, grid, opt.nofreq, opt.MAF, opt.nosub, device=device)
+        Scan(data, neut, sel, grid, outfile if world.rank == 0 else None, fixSize=opt.size, r=opt.w, s=opt.step, phys=opt.phys,
+             noCenter=opt.noCenter, runner=runner, verbose=False, keep_results=False, reuse_ctx=ctx)
+        ctx = sel.ctx
+        tables += 0 if sel.table_reused else 1
+        stamp('file %d of %d' % (i + 1, len(files)))
+    world.finish()
+    say(f'\n{datetime.now()}. Pipeline finished: {len(files)} files, selection table built {tables} time(s).')
 
 
 if __name__ == '__main__':

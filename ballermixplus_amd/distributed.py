@@ -83,8 +83,9 @@ class World:
     # ------------------------------------------------------------------ gather
     def gather_records(self, rec, counts, dst=0):
         """ONE gather of 16-byte records to rank `dst`.  `rec`: this rank's records, either a numpy structured
-        array (RECORD) or a torch int64 tensor of shape [n, 2] (a zero-copy view of the library's device records
-        for the nccl backend).  Returns a list of RECORD arrays, one per rank, on `dst`; None elsewhere."""
+        array (RECORD) or a torch int64 tensor of shape [n, 2] on the rank's GPU (nccl backend; it must not be
+        rewritten before this call returns: the call waits for the collective).  Returns a list of RECORD arrays, one
+        per rank, on `dst`; None elsewhere."""
         import torch
         import torch.distributed as dist
         pad = max(counts) if counts else 0
@@ -97,17 +98,24 @@ class World:
         if t.shape[0] < pad:
             t = torch.cat([t, torch.zeros((pad - t.shape[0], 2), dtype=torch.int64, device=dev)])
         t = t.contiguous()
-        bufs = [torch.empty((pad, 2), dtype=torch.int64, device=dev) for _ in range(self.size)] if self.rank == dst else None
-        dist.gather(t, bufs, dst=dst)
+        big = torch.empty((self.size, pad, 2), dtype=torch.int64, device=dev) if self.rank == dst else None
+        dist.gather(t, list(big.unbind(0)) if self.rank == dst else None, dst=dst)
+        if self.backend == 'nccl':
+            # the collective runs on torch's NCCL stream: nothing may touch `rec` (the library's buffers, on the library's
+            # stream) until it has finished
+            torch.cuda.current_stream().synchronize()
         if self.rank != dst:
             return None
-        return [b.cpu().numpy().view(RECORD).reshape(-1)[:counts[r]] for r, b in enumerate(bufs)]
+        got = big.cpu().numpy().view(RECORD).reshape(self.size, pad)
+        return [got[r, :counts[r]] for r in range(self.size)]
 
     # ------------------------------------------------------------------ runner
     def sharded_runner(self, compute=None, block=None):
         """A drop-in for engine.scan_batch that scans only this rank's test sites and gathers the records on
-        rank 0; the other ranks get None back (they write nothing).  `compute(sel, test_gen, lo, hi) -> (clr, lin, ns)`
-        defaults to the GPU scan; tests inject a CPU function to exercise the sharding on gloo."""
+        rank 0 with ONE gather; the other ranks get None back (they write nothing).  Rank 0 gets a GatheredRecords: the
+        per-rank record arrays as they arrived, which the native writer turns into rows directly (no reassembly in Python).
+        `compute(sel, test_gen, lo, hi) -> (clr, lin, ns)` defaults to the GPU scan; tests inject a CPU function to
+        exercise the sharding on gloo."""
         world = self
 
         def run(sel, test_gen, win_lo, win_hi):
@@ -115,7 +123,8 @@ class World:
             win_lo = np.asarray(win_lo, dtype=np.int64)
             win_hi = np.asarray(win_hi, dtype=np.int64)
             M = len(test_gen)
-            parts = assign(M, world.size, block)
+            blk = BLOCK if block is None else int(block)
+            parts = assign(M, world.size, blk)
             mine = parts[world.rank]
             counts = [len(p) for p in parts]
             if compute is not None:
@@ -125,11 +134,10 @@ class World:
             elif len(mine):
                 sel.ctx.set_tests(test_gen[mine], win_lo[mine], win_hi[mine])
                 sel.ctx.scan()
-                sel.ctx.sync()
                 if world.backend == 'nccl':
                     import torch
-                    rec = torch.as_tensor(_DevArray(sel.ctx.records(), 2 * len(mine), '<i8'),
-                                          device=torch.device('cuda', world.device_index))
+                    rec = torch.empty((len(mine), 2), dtype=torch.int64, device=torch.device('cuda', world.device_index))
+                    sel.ctx.pack_records(device_ptr=rec.data_ptr(), cap=len(mine))     # waits for the scan, device -> device
                 else:
                     rec = sel.ctx.fetch_records()
             else:
@@ -137,12 +145,34 @@ class World:
             got = world.gather_records(rec, counts)
             if got is None:
                 return None
-            out = np.empty(M, dtype=RECORD)
-            for r in range(world.size):
-                out[parts[r]] = got[r]
-            return unpack_lin(out['clr'].copy(), out['lin'], out['nsites'].copy(), len(sel.grid_x), len(sel.grid_abeta))
+            return GatheredRecords(got, M, blk, world.size, len(sel.grid_x), len(sel.grid_abeta))
 
         return run
+
+
+class GatheredRecords:
+    """What rank 0 holds after the gather of a sharded scan: per_rank[r] = RECORD array of rank r's test sites in its own
+    order (blocks of `block` test sites dealt round-robin)."""
+
+    def __init__(self, per_rank, M, block, world, nx, nab):
+        self.per_rank, self.M, self.block, self.world, self.nx, self.nab = per_rank, M, block, world, nx, nab
+
+    def in_order(self):
+        """One RECORD array in test-site order."""
+        out = np.empty(self.M, dtype=RECORD)
+        for r, p in enumerate(assign(self.M, self.world, self.block)):
+            out[p] = self.per_rank[r]
+        return out
+
+    def unpack(self):
+        """(clr, ix, ia, iA, nsites) as engine.scan_batch returns them."""
+        rec = self.in_order()
+        return unpack_lin(rec['clr'].copy(), rec['lin'], rec['nsites'].copy(), self.nx, self.nab)
+
+    def write(self, path, phys, gen, xs, abs_, As):
+        """Append the rows to `path` through the native writer, straight from the per-rank arrays."""
+        from . import _lib
+        _lib.write_records(path, phys, gen, self.per_rank, self.block, xs, abs_, As)
 
 
 def unpack_lin(clr, lin, ns, nx, nab):

@@ -245,17 +245,23 @@ class NormalizedBetaBinom:
         if self.ctx is not None and self.ctx is not reuse:
             self.ctx.close()
         akey = tuple(float(a) for a in self.grid_A)
-        if reuse is not None and getattr(reuse, 'model', None) is not None and reuse.model.key == self.model.key and \
-                getattr(reuse, 'A_key', None) == akey and reuse.device == self._device:
-            self.ctx = reuse
+        same_dev = reuse is not None and reuse.device == self._device
+        if same_dev and getattr(reuse, 'model', None) is not None and reuse.model.key == self.model.key and \
+                getattr(reuse, 'A_key', None) == akey:
+            self.ctx = reuse                      # same table: kept, only the site arrays are replaced
             self.ctx.model = self.model
+            self.table_reused = True
         else:
-            if self._fresh_ctx is not None and self._fresh_ctx.device == self._device:
+            if same_dev:
+                self.ctx = reuse                  # same GPU, another model (a chromosome with other sample sizes, another
+                                                  # minCount, ...): the context and its buffers are kept, the table is rebuilt
+            elif self._fresh_ctx is not None and self._fresh_ctx.device == self._device:
                 self.ctx, self._fresh_ctx = self._fresh_ctx, None
             else:
                 self.ctx = Context(self._device)
             self.ctx.set_model(self.model, self.grid_A)
             self.ctx.A_key = akey
+            self.table_reused = False
         self.ctx.set_sites(d.genPos, self.rows)
         self._bound_to = NeutralSFS
         self._psel = None

@@ -264,7 +264,7 @@ class Scan:
             say(('Computing LR on every %s site/s, using informative sites with exp(-A*dist) >= 1e-8.' % (s)))
             ts = sites_alpha(InputData, s)
         say(("writing output to %s" % (outfile)))
-        NormalizedBetaBinom.bind(NeutralSFS, reuse=reuse_ctx) if reuse_ctx is not None else NormalizedBetaBinom.bind(NeutralSFS)
+        NormalizedBetaBinom.bind(NeutralSFS, reuse=reuse_ctx)
         run = runner or engine.scan_batch
         streamed = False
         if len(ts):
@@ -282,6 +282,19 @@ class Scan:
         else:
             results = (np.zeros(0), np.zeros(0, int), np.zeros(0, int), np.zeros(0, int), np.zeros(0, int))
         self.test_sites = ts
+        if results is not None and hasattr(results, 'per_rank'):
+            # a sharded run's records on the writing rank: rows straight from the per-rank arrays (native writer) when the
+            # rows are plain (integer physPos, no NA rows); otherwise reassembled and written like any other result
+            if outfile is not None and ts.arrays is not None and not ts.na_rows and len(ts):
+                sel = NormalizedBetaBinom
+                with open(outfile, 'w') as scores:
+                    scores.write(HEADER)
+                results.write(outfile, ts.arrays[0], ts.arrays[1], [f'{v}' for v in sel.grid_x], [f'{v}' for v in sel.grid_abeta],
+                              [f'{v}' for v in sel.grid_A])
+                streamed = True
+                results = results.unpack() if keep_results else None
+            else:
+                results = results.unpack()
         self.results = results
         if outfile is not None and results is not None and not streamed:
             write_rows(outfile, ts, results, NormalizedBetaBinom)

@@ -56,7 +56,21 @@ def _worker(rank, world, port, q):
     res = run(Sel, ts.test_gen, ts.lo, ts.hi)
     assert seen == [len(parts[rank])]
     if rank == 0:
-        q.put([np.asarray(a) for a in res])
+        # rank 0 holds the per-rank record arrays as they arrived; rows come straight from them through the native writer
+        # (bmx_write_records), byte-identical to the rows of the reassembled arrays
+        import tempfile
+        from ballermixplus_amd import _lib
+        assert len(res.per_rank) == world and [len(a) for a in res.per_rank] == [len(p) for p in parts]
+        un = res.unpack()
+        sx, sab, sA = [repr(v) for v in case.xs], [repr(v) for v in case.abetas], [repr(v) for v in case.As]
+        phys = np.asarray(ts.phys, dtype=np.int64)
+        genl = np.asarray(ts.gen_label, dtype=np.float64)
+        with tempfile.TemporaryDirectory() as d:
+            a, b = os.path.join(d, 'a.txt'), os.path.join(d, 'b.txt')
+            res.write(a, phys, genl, sx, sab, sA)
+            _lib.write_rows(b, phys, genl, *un, sx, sab, sA)
+            assert open(a, 'rb').read() == open(b, 'rb').read() and os.path.getsize(a) > 30000
+        q.put([np.asarray(a) for a in un])
     else:
         assert res is None                 # only the writing rank holds the gathered rows
     w.finish()

@@ -280,27 +280,39 @@ def test_cli_two_ranks_on_one_gpu_write_the_single_rank_file(tmp_path):
 
 
 def test_bench_contract_two_ranks_on_one_gpu():
-    """bench.py (default workload: config 4, here a 1/100 genome) under torch.distributed.run with two ranks sharing this
-    box's one GPU (gloo gather through the host instead of RCCL): exit code 0, exactly ONE JSON line on stdout,
-    whole-job value over both ranks, strong scaling, the gather inside the step."""
+    """PLAIN `python bench.py --gpus 2 ...` -- no launcher: the parent, which never touches the GPU, starts the two ranks itself
+    (torch.distributed.run as a child) and relays their one JSON line.  Default workload (config 4, here a 1/100 genome), two
+    ranks sharing this box's one GPU (gloo gather through the host instead of RCCL): exit code 0, exactly ONE JSON line on
+    stdout, whole-job value over both ranks, strong scaling, ONE gather inside the step; same checksum and same number of
+    records as the one-rank run, step time within 25 % of it (both ranks' kernels share the one GPU)."""
     import json
     env = dict(os.environ, BMX_DIST_BACKEND='gloo', BMX_SINGLE_DEVICE='1')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', '29617', os.path.join(REPO, 'bench.py'),
-                        '--gpus', '2', '--steps', '1', '--warmup', '1', '--total-snps', '400000'],
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    common = ['--steps', '2', '--warmup', '1', '--total-snps', '400000', '--no-cpu-baseline']
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2'] + common,
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['steps'] == 1 and d['warmup'] == 1 and d['scaling'] == 'strong'
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'strong'
     assert d['unit'] == 'windows/s' and d['higher_is_better'] is True and d['vs_baseline'] is None
     W = d['config']['windows_per_step']
-    assert 399990 <= W <= 400010 and d['config']['launches_per_step'] == 22
+    assert 399990 <= W <= 400010 and d['config']['launches_per_step'] == 22 and d['config']['records_per_step'] == W
     assert abs(d['value'] - W / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    assert 'ONE gather' in d['config']['parallelism']
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in d['roofline']
     assert 'cpu_baseline' not in d            # reported at N = 1 only
+    r1 = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + common, capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads([l for l in r1.stdout.splitlines() if l.strip()][-1])
+    assert d1['n_gpus'] == 1 and d1['config']['records_per_step'] == W
+    assert d1['config']['checksum_clr'] == pytest.approx(d['config']['checksum_clr'], rel=1e-12)    # same rows, summed in another order
+    assert d1['config']['input_sha256'] == d['config']['input_sha256']
+    print('bench step: 2 ranks on one GPU %.1f ms, 1 rank %.1f ms (ratio %.3f)' % (d['ms_per_step'], d1['ms_per_step'], d['ms_per_step'] / d1['ms_per_step']))
+    assert d['ms_per_step'] < 1.25 * d1['ms_per_step']
 
 
 # ------------------------------------------------------------------------------------------------ configs 4 and 5 at size
@@ -383,11 +395,13 @@ def test_config4_whole_genome_on_one_context():
         assert os.path.exists(os.path.join(GOLD, 'synth', 'config4_chr%d_step50000.tsv' % cc)), 'reference fixture missing'
 
 
-def test_config5_two_contigs_at_full_size():
-    """BASELINE config 5 at its contig size: 2 of the 8 contigs of 1.25M SNPs, n = 200, A = 100..10000 step 100,
-    --findBal --findPos (100 x 10 x 44), every SNP a test site, helper file from the concatenation of all 8 contigs.
-    Reference rows (tests/golden/synth/config5_contig{1,2}_step125000.tsv) exact in (x, alpha, A, nSites), CLR to 1e-6;
-    a block of 4096 consecutive windows per contig equals the per-site kernel's (variant 2) argmax and nSites."""
+def test_config5_in_full():
+    """BASELINE config 5 in full: 10M SNPs as 8 contigs of 1.25M, n = 200, A = 100..10000 step 100, --findBal --findPos
+    (100 x 10 x 44), every SNP a test site, helper file from the concatenation of all 8 contigs -- ONE context, one slot per
+    contig, the eight scans launched back to back, one pack of all 10M records.  Reference rows
+    (tests/golden/synth/config5_contig{1,2}_step125000.tsv) exact in (x, alpha, A, nSites), CLR to 1e-6; a block of 4096
+    consecutive windows on contigs 1 and 2 equals the per-site kernel's (variant 2) argmax and nSites; contigs 5 and 8 are
+    bitwise equal to a fresh context's."""
     from ballermixplus_amd import engine as eng, synth
     from ballermixplus_amd.hostmodel import Grids
     data = [synth.synth_chromosome(1250000, 200, c + 1) for c in range(8)]
@@ -398,15 +412,28 @@ def test_config5_two_contigs_at_full_size():
     model = eng.ModelArrays('B2', 1, [200], spect, {200: 1.0}, xs, ab)
     ctx = eng.Context(0)
     ctx.set_model(model, As)
+    for c in range(8):
+        phys, gen, k, nn = data[c]
+        N = len(gen)
+        ctx.select_slot(c)
+        ctx.set_sites(gen, model.rows_of(k, nn))
+        ctx.set_tests(gen, np.zeros(N, np.int64), np.full(N, N - 1, np.int64))
+    for c in range(8):
+        ctx.select_slot(c)
+        ctx.scan()
+    rec = ctx.pack_records()
+    assert len(rec) == 10000000 and np.all(np.isfinite(rec['clr'])) and np.all(rec['clr'] >= 0)
+    print('config 5 in full: %d windows scanned on one context (8 slots)' % len(rec))
+    npairs = len(xs) * len(ab)
     found = 0
     for c in (1, 2):
         phys, gen, k, nn = data[c - 1]
         N = len(gen)
-        ctx.set_sites(gen, model.rows_of(k, nn))
-        ctx.set_tests(gen, np.zeros(N, np.int64), np.full(N, N - 1, np.int64))
-        ctx.scan()
+        ctx.select_slot(c - 1)
         clr, ix, ia, iA, ns = ctx.fetch()
-        assert len(clr) == N and np.all(np.isfinite(clr)) and np.all(clr >= 0)
+        r = rec[(c - 1) * N:c * N]
+        lin = np.where(iA < 0, -1, iA * npairs + ix * len(ab) + ia)
+        assert np.array_equal(r['clr'], clr) and np.array_equal(r['lin'], lin) and np.array_equal(r['nsites'], ns)
         path = os.path.join(GOLD, 'synth', 'config5_contig%d_step125000.tsv' % c)
         if os.path.exists(path):
             found += 1
@@ -420,6 +447,17 @@ def test_config5_two_contigs_at_full_size():
         ctx.set_variant(0)
         assert np.array_equal(ix2, ix[blk]) and np.array_equal(ia2, ia[blk]) and np.array_equal(iA2, iA[blk]) and np.array_equal(ns2, ns[blk])
         assert np.max(np.abs(c2 - clr[blk]) / np.maximum(clr[blk], 1e-9)) < 1e-9
+    for c in (5, 8):
+        phys, gen, k, nn = data[c - 1]
+        N = len(gen)
+        fresh = eng.Context(0)
+        fresh.set_model(model, As)
+        fresh.set_sites(gen, model.rows_of(k, nn))
+        fresh.set_tests(gen, np.zeros(N, np.int64), np.full(N, N - 1, np.int64))
+        fresh.scan()
+        want = fresh.fetch_records()
+        fresh.close()
+        assert np.array_equal(rec[(c - 1) * N:c * N], want), c
     ctx.close()
     assert found == 2, 'reference fixtures missing'
 

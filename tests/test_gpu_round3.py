@@ -1,0 +1,248 @@
+"""GPU tests added in round 3: the prepared pipeline (prep_kernel + clr_scan_prepared_kernel) against the round-2 grouped
+kernel, the per-site kernel and the reference's rows; chromosome slots of one context; the multi-file CLI form; the per-site
+kernel on grids of more than 8191 A values; the plan query."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+from util import GOLD, REFT, REPO, c_oracle, c_scan, read_tsv
+
+pytestmark = pytest.mark.gpu
+
+
+def _synth_model(n=100, chroms=((1, 200000),), bal=False):
+    from ballermixplus_amd import engine as eng, synth
+    from ballermixplus_amd.hostmodel import Grids
+    data = [synth.synth_chromosome(N, n, c) for c, N in chroms]
+    kk, nk = np.concatenate([d[2] for d in data]), np.concatenate([d[3] for d in data])
+    spect = {(a, b): f for a, b, f in synth.spect_from_counts(kk, nk)}
+    grid = Grids(None, None, True, True, '100,10000,100', None) if bal else Grids(None, None, False, False, None, None)
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays('B2', int(kk.min()), [n], spect, {n: 1.0}, xs, ab)
+    return eng, data, model, (xs, ab, As)
+
+
+def test_plan_names_the_kernel_that_runs():
+    """bmx_ctx_plan: dense test sites -> prepared pipeline, J = 16, table in LDS; every 40th SNP -> J = 4; every 200th -> the
+    per-site kernel; variant 12 -> the round-2 grouped kernel; 41 sample sizes -> table from global memory."""
+    eng, data, model, (xs, ab, As) = _synth_model()
+    phys, gen, k, nn = data[0]
+    N = len(gen)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, model.rows_of(k, nn))
+    want = {1: ('clr_scan_prepared_kernel<16,true>', 4), 10: ('clr_scan_prepared_kernel<8,true>', 4),
+            40: ('clr_scan_prepared_kernel<4,true>', 4), 200: ('clr_scan_kernel<true>', -1)}
+    for step, (name, mode) in want.items():
+        idx = np.arange(0, N, step)
+        ctx.set_tests(gen[idx], np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64))
+        pl = ctx.plan()
+        assert pl['kernel'] == name and pl['mode'] == mode, (step, pl)
+        assert (pl['stream_bytes'] > 0) == (mode == 4)
+    ctx.set_variant(12)
+    idx = np.arange(0, N)
+    ctx.set_tests(gen[idx], np.zeros(N, np.int64), np.full(N, N - 1, np.int64))
+    assert ctx.plan()['kernel'] == 'clr_scan_grouped_kernel<16,true,3>'
+    ctx.close()
+
+
+@pytest.mark.parametrize('step,J', [(1, 16), (2, 16), (5, 8), (30, 4)])
+def test_prepared_pipeline_equals_round2_kernel_and_oracle(step, J):
+    """The prepared pipeline (variant 0) against the round-2 grouped kernel (variant 12: same group size) on 32k config-3
+    windows at several test-site strides: identical argmax and nSites, CLR to 1e-10 (the two differ only in which sites
+    count as far: one threshold per row instead of one per row and slice); and against the C oracle on a sample."""
+    eng, data, model, (xs, ab, As) = _synth_model(chroms=((1, 400000),))
+    phys, gen, k, nn = data[0]
+    N = len(gen)
+    rows = model.rows_of(k, nn)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, rows)
+    M = 32768 // max(1, step // 2)
+    idx = 50000 + step * np.arange(M)
+    idx = idx[idx < N - 1000]
+    M = len(idx)
+    lo, hi = np.zeros(M, np.int64), np.full(M, N - 1, np.int64)
+    out = {}
+    for v in (0, 12):
+        ctx.set_variant(v)
+        ctx.set_tests(gen[idx], lo, hi)
+        assert ctx.plan()['J'] == J
+        ctx.scan()
+        out[v] = ctx.fetch()
+    for a, b in zip(out[0][1:], out[12][1:]):
+        assert np.array_equal(a, b)
+    assert np.max(np.abs(out[0][0] - out[12][0]) / np.maximum(np.abs(out[12][0]), 1e-9)) < 1e-10
+    _, R = ctx.fetch_lut()
+    samp = np.arange(0, M, max(1, M // 48))
+    ref = c_scan(c_oracle(), np.where(np.isfinite(R), R, 0.0), As, gen, rows, gen[idx[samp]], lo[samp], hi[samp])
+    for q in (1, 2, 3, 4):
+        assert np.array_equal(out[0][q][samp], ref[q])
+    assert np.allclose(out[0][0][samp], ref[0], rtol=1e-9, atol=1e-12)
+    ctx.close()
+
+
+def test_prepared_pipeline_windows_and_partial_groups():
+    """Window modes through the prepared pipeline: -w index windows, windows that end inside the near field, a partial last group,
+    and two scans of the same test sites are bitwise equal (the stream is rebuilt per scan)."""
+    eng, data, model, (xs, ab, As) = _synth_model(chroms=((3, 120000),))
+    phys, gen, k, nn = data[0]
+    N = len(gen)
+    rows = model.rows_of(k, nn)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, rows)
+    _, R = ctx.fetch_lut()
+    Rf = np.where(np.isfinite(R), R, 0.0)
+    L = c_oracle()
+    for r in (3, 40, 700, 30000):
+        idx = np.arange(20000, 20000 + 1003)                 # 1003 = 62 groups of 16 + 11
+        lo = np.maximum(idx - r, 0).astype(np.int64)
+        hi = np.minimum(idx + r + 1, N - 1).astype(np.int64)
+        ctx.set_tests(gen[idx], lo, hi)
+        assert ctx.plan()['mode'] == 4
+        ctx.scan()
+        got = ctx.fetch()
+        ctx.scan()
+        again = ctx.fetch()
+        assert all(np.array_equal(a, b) for a, b in zip(got, again))
+        ref = c_scan(L, Rf, As, gen, rows, gen[idx], lo, hi)
+        for q in (1, 2, 3, 4):
+            assert np.array_equal(got[q], ref[q]), (r, q)
+        assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-12)
+    ctx.close()
+
+
+def test_slots_scanned_back_to_back_equal_separate_contexts():
+    """One context, three chromosome slots (different lengths), scans launched back to back without waiting, ONE pack of all
+    records -- bitwise what three separate contexts return; re-setting a slot's test sites drops only that slot's results; a new
+    model drops every slot."""
+    from ballermixplus_amd import _lib
+    eng, data, model, (xs, ab, As) = _synth_model(chroms=((5, 90000), (6, 30000), (7, 120000)))
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    Ms = (40000, 30000, 50001)
+    for c, (d, M) in enumerate(zip(data, Ms)):
+        phys, gen, k, nn = d
+        ctx.select_slot(c)
+        ctx.set_sites(gen, model.rows_of(k, nn))
+        ctx.set_tests(gen[:M], np.zeros(M, np.int64), np.full(M, len(gen) - 1, np.int64))
+    for c in range(3):
+        ctx.select_slot(c)
+        ctx.scan()
+    rec = ctx.pack_records()
+    assert len(rec) == sum(Ms)
+    at = 0
+    for c, (d, M) in enumerate(zip(data, Ms)):
+        phys, gen, k, nn = d
+        one = eng.Context(0)
+        one.set_model(model, As)
+        one.set_sites(gen, model.rows_of(k, nn))
+        one.set_tests(gen[:M], np.zeros(M, np.int64), np.full(M, len(gen) - 1, np.int64))
+        one.scan()
+        want = one.fetch_records()
+        one.close()
+        assert np.array_equal(rec[at:at + M], want), c
+        ctx.select_slot(c)
+        assert np.array_equal(ctx.fetch_records(), want)
+        at += M
+    # new test sites for slot 1: its results are gone, the others stay
+    ctx.select_slot(1)
+    ctx.set_tests(data[1][1][:100], np.zeros(100, np.int64), np.full(100, len(data[1][1]) - 1, np.int64))
+    with pytest.raises(_lib.BmxError) as e:
+        ctx.fetch_records()
+    assert e.value.code == -5
+    assert len(ctx.pack_records()) == Ms[0] + Ms[2]
+    ctx.set_model(model, As)                  # a new model: every slot's sites and tests are dropped
+    for c in range(3):
+        ctx.select_slot(c)
+        with pytest.raises(_lib.BmxError) as e:
+            ctx.set_tests(data[c][1][:10], np.zeros(10, np.int64), np.full(10, 5, np.int64))
+        assert e.value.code == -5
+    ctx.close()
+
+
+def test_per_site_kernel_with_more_than_8191_A_values():
+    """nA = 9000 (e.g. --rangeA 1,9000,1): the grouped kernels pack the winning A index into 13 bits and are not used; the
+    per-site kernel keeps it in a register of its own.  One grid pair (--fixX --fixAlpha), the winner must come from beyond
+    index 8191 on some test sites, against the C oracle."""
+    from ballermixplus_amd import engine as eng
+    rng = np.random.default_rng(5)
+    N, n = 600, 50
+    gen = np.cumsum(rng.geometric(0.2, N)).astype(np.float64) * 1e-6
+    k = rng.integers(1, n + 1, N)
+    nn = np.full(N, n)
+    cnt = {}
+    for a in k.tolist():
+        cnt[(a, n)] = cnt.get((a, n), 0) + 1
+    spect = {key: v / N for key, v in cnt.items()}
+    As = [float(v) for v in np.linspace(1e5, 10.0, 9000)]        # descending: large A first, so late indices hold the wide windows
+    model = eng.ModelArrays('B2', int(k.min()), [n], spect, {n: 1.0}, [0.3], [10.0])
+    rows = model.rows_of(k, nn)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, rows)
+    idx = np.arange(0, N, 7)
+    lo, hi = np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64)
+    ctx.set_tests(gen[idx], lo, hi)
+    assert ctx.plan()['kernel'].startswith('clr_scan_kernel')
+    ctx.scan()
+    got = ctx.fetch()
+    _, R = ctx.fetch_lut()
+    ref = c_scan(c_oracle(), np.where(np.isfinite(R), R, 0.0), As, gen, rows, gen[idx], lo, hi)
+    for q in (1, 2, 3, 4):
+        assert np.array_equal(got[q], ref[q])
+    assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-12)
+    assert np.max(got[3]) > 8191
+    ctx.close()
+
+
+def _cli(args, env=None):
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'BalLeRMixPlus_amd.py')] + args, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return r
+
+
+def test_cli_several_input_files_in_one_process(tmp_path):
+    """The multi-file form (-i a,b,c / --inputs list, -o directory or pattern): three chromosomes in one process on one
+    context -- byte-identical to three single-file runs; the table is built once while the model stays the same and rebuilt
+    for a file with another sample size."""
+    from ballermixplus_amd import helpers, synth
+    files, cat = [], tmp_path / 'all.txt'
+    with open(cat, 'w') as fc:
+        fc.write('physPos\tgenPos\tx\tn\n')
+        for c, (N, n) in enumerate(((30000, 100), (12000, 100), (20000, 100), (9000, 60)), start=1):
+            phys, gen, k, nn = synth.synth_chromosome(N, n, 20 + c)
+            p = tmp_path / ('chr%d.txt' % c)
+            synth.write_input(str(p), phys, gen, k, nn)
+            fc.write(''.join(open(p).readlines()[1:]))
+            files.append(str(p))
+    sp = tmp_path / 'spect.txt'
+    helpers.getSpect(str(cat), str(sp), False, False)
+    single = []
+    for f in files:
+        o = f + '.single'
+        _cli(['-i', f, '--spect', str(sp), '-o', o])
+        single.append(open(o, 'rb').read())
+    outdir = tmp_path / 'out'
+    r = _cli(['-i', ','.join(files), '--spect', str(sp), '-o', str(outdir)])
+    assert 'selection table built 2 time(s)' in r.stdout            # chr1-3 share n = 100; chr4 has n = 60
+    for f, want in zip(files, single):
+        assert open(outdir / (os.path.basename(f) + '.out.txt'), 'rb').read() == want
+    lst = tmp_path / 'list.txt'
+    lst.write_text('\n'.join(files[:3]) + '\n')
+    r = _cli(['--inputs', str(lst), '--spect', str(sp), '-o', str(tmp_path / 'pat_{}.tsv'), '-s', '3'])
+    assert 'selection table built 1 time(s)' in r.stdout
+    for f in files[:3]:
+        o = f + '.s3'
+        _cli(['-i', f, '--spect', str(sp), '-o', o, '-s', '3'])
+        stem = os.path.splitext(os.path.basename(f))[0]
+        assert open(tmp_path / ('pat_%s.tsv' % stem), 'rb').read() == open(o, 'rb').read()
+    # the one-file form is untouched, and a reference command line still works as it is
+    assert subprocess.run([sys.executable, os.path.join(REPO, 'BalLeRMixPlus_amd.py'), '-i', files[0] + ',' + files[1], '--spect', str(sp)],
+                          capture_output=True, text=True).returncode != 0      # several files need -o
