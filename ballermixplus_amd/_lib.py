@@ -51,6 +51,8 @@ PROTOTYPES = {
     'bmx_lut_build': (C.c_int, [C.POINTER(BmxModel), _dp, _dp, C.c_int]),
     'bmx_scan': (C.c_int, [C.POINTER(BmxModel), _dp, C.c_int32, C.c_int64, _dp, _ip, C.c_int64, _dp, _lp, _lp,
                            _dp, _ip, _ip, _ip, _ip, C.c_int]),
+    'bmx_scan_multi': (C.c_int, [C.POINTER(BmxModel), _dp, C.c_int32, C.c_int64, _dp, _ip, C.c_int64, _dp, _lp, _lp,
+                                 _dp, _ip, _ip, _ip, _ip, C.c_int32, _ip]),
     'bmx_ctx_create': (C.c_int, [C.POINTER(_vp), C.c_int]),
     'bmx_ctx_destroy': (None, [_vp]),
     'bmx_ctx_set_model': (C.c_int, [_vp, C.POINTER(BmxModel), _dp, C.c_int32]),

@@ -3570,4 +3570,58 @@ int bmx_scan(const bmx_model *m, const double *A, int32_t nA, int64_t N, const d
     return rc;
 }
 
+
+/* bmx_scan on several GPUs of this node, inside the library (no torch, no process group): one host thread and one context
+ * per entry of `devices` (NULL: 0 .. n_devices-1; an index may repeat -- two contexts on one GPU), test sites dealt to the
+ * workers in blocks of 4096 consecutive test sites round-robin -- the sharding of ballermixplus_amd/distributed.py, so every
+ * row is bitwise what one GPU computes -- and each worker's results copied into the caller's buffers. */
+int bmx_scan_multi(const bmx_model *m, const double *A, int32_t nA, int64_t N, const double *genpos,
+                   const int32_t *row, int64_t M, const double *test_gen, const int64_t *win_lo,
+                   const int64_t *win_hi, double *clr, int32_t *ix, int32_t *ia, int32_t *iA,
+                   int32_t *nsites, int32_t n_devices, const int32_t *devices) {
+    if (n_devices < 1 || n_devices > 64) return fail(BMX_E_INVALID, "n_devices must be 1..64");
+    if (M < 1 || !test_gen || !win_lo || !win_hi) return fail(BMX_E_INVALID, "empty test-site arrays");
+    constexpr int64_t BLOCK = 4096;
+    const int64_t nblk = (M + BLOCK - 1) / BLOCK;
+    std::vector<int> rcs((size_t)n_devices, BMX_OK);
+    std::vector<std::string> msgs((size_t)n_devices);
+    auto work = [&](int w) {
+        // this worker's test sites: blocks w, w + n, w + 2n, ...
+        std::vector<int64_t> idx;
+        for (int64_t b = w; b < nblk; b += n_devices)
+            for (int64_t t = b * BLOCK; t < std::min((b + 1) * BLOCK, M); ++t) idx.push_back(t);
+        if (idx.empty()) return;
+        const size_t n = idx.size();
+        std::vector<double> tg(n), c_(n);
+        std::vector<int64_t> lo(n), hi(n);
+        std::vector<int32_t> x_(n), a_(n), A_(n), ns_(n);
+        for (size_t i = 0; i < n; ++i) { tg[i] = test_gen[idx[i]]; lo[i] = win_lo[idx[i]]; hi[i] = win_hi[idx[i]]; }
+        bmx_ctx *c = nullptr;
+        int rc = bmx_ctx_create(&c, devices ? devices[w] : w);
+        if (!rc) rc = bmx_ctx_set_model(c, m, A, nA);
+        if (!rc) rc = bmx_ctx_set_sites(c, N, genpos, row);
+        if (!rc) rc = bmx_ctx_set_tests(c, (int64_t)n, tg.data(), lo.data(), hi.data());
+        if (!rc) rc = bmx_ctx_scan(c);
+        if (!rc) rc = bmx_ctx_fetch(c, c_.data(), x_.data(), a_.data(), A_.data(), ns_.data());
+        if (rc) msgs[(size_t)w] = bmx_last_error();          // this thread's message
+        bmx_ctx_destroy(c);
+        rcs[(size_t)w] = rc;
+        if (rc) return;
+        for (size_t i = 0; i < n; ++i) {
+            const int64_t t = idx[i];
+            if (clr) clr[t] = c_[i];
+            if (ix) ix[t] = x_[i];
+            if (ia) ia[t] = a_[i];
+            if (iA) iA[t] = A_[i];
+            if (nsites) nsites[t] = ns_[i];
+        }
+    };
+    std::vector<std::thread> th;
+    for (int w = 0; w < n_devices; ++w) th.emplace_back(work, w);
+    for (auto &t : th) t.join();
+    for (int w = 0; w < n_devices; ++w)
+        if (rcs[(size_t)w]) return fail(rcs[(size_t)w], "worker " + std::to_string(w) + ": " + msgs[(size_t)w]);
+    return BMX_OK;
+}
+
 }  // extern "C"

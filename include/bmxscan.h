@@ -111,6 +111,15 @@ int bmx_scan(const bmx_model *m, const double *A, int32_t nA, int64_t N, const d
              const int64_t *win_hi, double *clr, int32_t *ix, int32_t *ia, int32_t *iA,
              int32_t *nsites, int device);
 
+/* bmx_scan on several GPUs of this node, inside the library (no Python, no torch, no process group): one host thread and
+ * one context per entry of devices[n_devices] (NULL: GPUs 0 .. n_devices-1; an index may repeat), test sites dealt to the
+ * workers in blocks of 4096 consecutive test sites round-robin, each worker's results copied into the caller's buffers.
+ * Every output row is bitwise what bmx_scan returns on one GPU (a window's arithmetic never depends on the sharding). */
+int bmx_scan_multi(const bmx_model *m, const double *A, int32_t nA, int64_t N, const double *genpos,
+                   const int32_t *row, int64_t M, const double *test_gen, const int64_t *win_lo,
+                   const int64_t *win_hi, double *clr, int32_t *ix, int32_t *ia, int32_t *iA,
+                   int32_t *nsites, int32_t n_devices, const int32_t *devices);
+
 /* ---- resident-context entry points ------------------------------------------------- */
 /* Same computation split so that inputs stay resident in HBM across scans (one context per
  * process per GPU; the multi-GPU driver shards test sites across processes).

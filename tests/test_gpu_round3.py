@@ -246,3 +246,41 @@ def test_cli_several_input_files_in_one_process(tmp_path):
     # the one-file form is untouched, and a reference command line still works as it is
     assert subprocess.run([sys.executable, os.path.join(REPO, 'BalLeRMixPlus_amd.py'), '-i', files[0] + ',' + files[1], '--spect', str(sp)],
                           capture_output=True, text=True).returncode != 0      # several files need -o
+
+
+def test_library_level_multi_gpu_one_shot():
+    """bmx_scan_multi (threads + one context per device inside libbmxscan.so, test sites dealt in blocks of 4096): with one
+    worker, and with two and three workers that all use this box's one GPU, bitwise what bmx_scan returns; a bad device index
+    is reported from the worker that hit it."""
+    import ctypes as C
+    from ballermixplus_amd import _lib
+    eng, data, model, (xs, ab, As) = _synth_model(chroms=((4, 60000),))
+    phys, gen, k, nn = data[0]
+    N = len(gen)
+    rows = model.rows_of(k, nn)
+    M = 3 * 4096 + 777
+    idx = 10000 + np.arange(M)
+    tg = _lib.f64(gen[idx])
+    lo, hi = np.zeros(M, np.int64), np.full(M, N - 1, np.int64)
+    A = _lib.f64(As)
+    L = _lib.lib()
+
+    def call(fn, *tail):
+        clr = np.empty(M)
+        ix, ia, iA, ns = (np.empty(M, np.int32) for _ in range(4))
+        rc = fn(C.byref(model.c), _lib.as_dp(A), len(A), N, _lib.as_dp(_lib.f64(gen)), _lib.as_ip(rows), M, _lib.as_dp(tg),
+                _lib.as_lp(lo), _lib.as_lp(hi), _lib.as_dp(clr), _lib.as_ip(ix), _lib.as_ip(ia), _lib.as_ip(iA), _lib.as_ip(ns), *tail)
+        return rc, (clr, ix, ia, iA, ns)
+
+    rc, want = call(L.bmx_scan, 0)
+    assert rc == 0
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        d = _lib.i32(devs)
+        rc, got = call(L.bmx_scan_multi, len(devs), _lib.as_ip(d))
+        assert rc == 0, L.bmx_last_error()
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), devs
+    rc, got = call(L.bmx_scan_multi, 1, None)          # devices = NULL: GPU 0
+    assert rc == 0 and all(np.array_equal(a, b) for a, b in zip(got, want))
+    d = _lib.i32([0, 99])
+    rc, _ = call(L.bmx_scan_multi, 2, _lib.as_ip(d))
+    assert rc == -2 and b'worker 1' in L.bmx_last_error()
