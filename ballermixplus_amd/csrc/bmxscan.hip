@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 #include <string>
 #include <thread>
 #include <unordered_set>
@@ -98,6 +99,9 @@ constexpr int MOM_SLOTS_LDS = 64;             // ... of which this many are used
 #endif
 #ifndef BMX_MIDTRI
 #define BMX_MIDTRI 1
+#endif
+#ifndef BMX_XCD_MAP
+#define BMX_XCD_MAP 1     // prepared kernel: the slices of a chunk of test sites on one XCD (4.168 -> 4.205 M windows/s, HBM reads / 8)
 #endif
 #ifndef BMX_PRIV01
 #define BMX_PRIV01 1
@@ -1336,13 +1340,15 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 // pair-parallel kernel needs as one sequential stream per group ("blob") in HBM; clr_scan_prepared_kernel -- one wave per
 // (group, slice) as before -- then only multiplies, folds and flushes, reading its blob through a ring in LDS.
 //
-//   blob(group)  = for iA in 0..nA-1: zone(iA, right), zone(iA, left);   16-byte units, padded to a multiple of 4
-//   zone         = header (3 units): {magic | rag, n_pair, n_quad, n_occ} {n_far, n_rag, end index | ZONE_DONE, tag} {n_j bytes}
+//   blob(group)  = for iA in 0..nA-1: near(iA, right), near(iA, left), far(iA, right), far(iA, left);   16-byte units,
+//                  padded to a multiple of 4
+//   near(zone)   = header (3 units): {magic | rag, n_pair, n_quad, n_occ} {n_far, n_rag, end index | ZONE_DONE, tag} {n_j bytes}
 //                  near list: n_pair entries with alpha > 1/2 (padded to whole blocks), then n_quad entries (multiple of 4),
 //                             each (E_i f64, row offset i32), in walk order; 8 neutral guard entries (what the block loops
 //                             request one block ahead)
-//                  moments:   n_occ entries of 5 units: (M_1, row offset) (M_2, M_3) (M_4, M_5) (M_6, M_7) (M_8, -)
+//   far(zone)    = moments:   n_occ entries of 5 units: (M_1, row offset) (M_2, M_3) (M_4, M_5) (M_6, M_7) (M_8, -)
 //                  ragged end (rag only): n_rag entries (E, row offset) + 1 guard
+//   (both near lists first: the consumer multiplies, then takes ONE exp per test site for the two far fields together)
 // Sizes come from a counting pass of the same code (prep_kernel<J, false>: identical predicates, no exp, no stores) run when
 // the test sites are set, then an exclusive scan; the fill pass (prep_kernel<J, true>) and the consumer run per launch range.
 // The far test is slice-independent now: alpha * max_grid |R[row]| <= far_eps, evaluated in the exponent domain
@@ -1353,6 +1359,7 @@ constexpr int RING_UNITS = 256, RING_MIRROR = 16, AUX_UNITS = 32;     // per wav
 constexpr int PREP_ZONE_DONE = -0x7fffffff;
 constexpr int PREP_THREADS = 256;
 constexpr int PREP_THR_LDS_MAX = 4096;                                // rows whose far thresholds are staged in LDS
+constexpr int64_t SOLO_GAP = 56;                                      // median gap between test sites beyond which groups stop paying
 
 struct PrepParams {
     const double *genpos;
@@ -1390,10 +1397,13 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
         for (int idx = threadIdx.x; idx < P.rows; idx += blockDim.x) lds_p[idx] = P.rowthr[idx];
         __syncthreads();
     }
+    // per wave: the moments of the right and of the left zone of one A (the stream holds both zones' near lists before either
+    // zone's moments, so the right zone's sums wait while the left zone is walked), then 64 doubles of scratch
     const int mom_len = (P.mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER;
-    double *mom = lds_p + thr_len + wave * (mom_len + WAVE);
-    double *ragscr = mom + mom_len;
-    for (int idx = lane; idx < mom_len; idx += WAVE) mom[idx] = 0.0;
+    double *mom_r = lds_p + thr_len + wave * (2 * mom_len + WAVE);
+    double *mom_l = mom_r + mom_len;
+    double *ragscr = mom_l + mom_len;
+    for (int idx = lane; idx < 2 * mom_len; idx += WAVE) mom_r[idx] = 0.0;
     __builtin_amdgcn_wave_barrier();
     const int64_t grp = P.g_begin + (int64_t)blockIdx.x * nw + wave;
     if (grp >= P.g_end) return;                     // (no workgroup barrier below this line)
@@ -1434,7 +1444,10 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
     for (int iA = 0; iA < P.nA; ++iA) {
         const double A = P.A[iA];
         const int kmom = min((int)P.kmom[iA], P.mom_slots);
-        auto zone = [&](int base, int dir, double tnear, double tfar, int tag) {
+        // One zone, first half: header slot, near list (pairs, then quads), guard; the far sites' moments go to `mom`; the
+        // ragged end is sized.  What the second half needs comes back through the reference arguments.
+        auto zone_near = [&](int base, int dir, double tnear, double tfar, double *mom, int &zbase_o, int &npp_o, int &nqp_o, int &nfar_o,
+                             int &base_o, double &m1p_o, double &m2p_o, int &nragv_o, int &nrmax_o, bool &rag_o, double &zr_o, int &rr_o) {
             const int zbase = wpos, nbase = zbase + PREP_HDR;
             int n_pair = 0, n_pair_pad = 0, n_quad = 0, nfar_tot = 0, pad_ro = 0;
             bool pair_open = true, seen = false;
@@ -1562,8 +1575,12 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                     rag = __ballot(far3) == ~0ull;
                 }
             }
-
-            // moments of the occupied slots, slot order
+            zbase_o = zbase; npp_o = n_pair_pad; nqp_o = n_quad_pad; nfar_o = nfar_tot; base_o = base; m1p_o = m1p; m2p_o = m2p;
+            nragv_o = nrag_v; nrmax_o = nrmax; rag_o = rag; zr_o = zr; rr_o = rr;
+        };
+        // ... second half: the moments of the occupied slots (slot order), the ragged end's entries, and the header
+        auto zone_far = [&](double *mom, int zbase, int n_pair_pad, int n_quad_pad, int nfar_tot, int base, double m1p, double m2p,
+                            int nrag_v, int nrmax, bool rag, double zr, int rr, int tag) {
             int n_occ = 0;
             if (nfar_tot) {
                 __builtin_amdgcn_wave_barrier();
@@ -1653,8 +1670,15 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                 }
             }
         };
-        zone(R_int, +1, tL, t0, iA * 2);
-        zone(L_int - 1, -1, t0, tL, iA * 2 + 1);
+        // stream order: both zones' near lists, then both zones' far fields (the consumer multiplies first and takes ONE exp
+        // per test site for the two far fields together)
+        int zbR, nppR, nqpR, nfR, beR, nrvR, nrmR, rrR, zbL, nppL, nqpL, nfL, beL, nrvL, nrmL, rrL;
+        bool ragR, ragL;
+        double m1R, m2R, zrR, m1L, m2L, zrL;
+        zone_near(R_int, +1, tL, t0, mom_r, zbR, nppR, nqpR, nfR, beR, m1R, m2R, nrvR, nrmR, ragR, zrR, rrR);
+        zone_near(L_int - 1, -1, t0, tL, mom_l, zbL, nppL, nqpL, nfL, beL, m1L, m2L, nrvL, nrmL, ragL, zrL, rrL);
+        zone_far(mom_r, zbR, nppR, nqpR, nfR, beR, m1R, m2R, nrvR, nrmR, ragR, zrR, rrR, iA * 2);
+        zone_far(mom_l, zbL, nppL, nqpL, nfL, beL, m1L, m2L, nrvL, nrmL, ragL, zrL, rrL, iA * 2 + 1);
     }
     const int units = (wpos + 3) & ~3;
     if (!FILL) {
@@ -1700,8 +1724,18 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
     constexpr int BS = J >= 16 ? 4 : 8;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#if BMX_XCD_MAP
+    // The slices of one chunk of test sites read the SAME blobs: put them on one XCD (workgroups go to the XCDs round-robin,
+    // b % 8), next to each other in its dispatch order, so that one of them brings a blob into the XCD's L2 and the others hit.
+    // (The host pads the number of chunks to a multiple of 8; padding chunks have no groups.)
+    const int xcd = blockIdx.x & 7;
+    const int64_t q = blockIdx.x >> 3;
+    const int slice = (int)(q % P.nslices);
+    const int64_t chunk = (q / P.nslices) * 8 + xcd;
+#else
     const int slice = blockIdx.x % P.nslices;
     const int64_t chunk = blockIdx.x / P.nslices;
+#endif
     const int p = slice * WAVE + lane;
     const int jl = lane % J, sl = lane / J;
     const int N = (int)P.N;
@@ -1869,12 +1903,16 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 return generic_core(i, inr, g, rowoff, dir);
             };
 
-            // one zone of the blob: near-list products, fold of the moments, flush; returns where the generic walk goes on
-            auto bulk_zone = [&](int dir, double tnear) -> int {
+            // One zone of the blob, first half: header and near-list products; returns where the generic walk goes on.  What
+            // the far half needs later (after BOTH near lists) comes back through the references; fv: lane j holds F_j.
+            auto zone_near = [&](int dir, double tnear, double &fv_o, int &nocc_o, int &nfar_o, int &nrmax_o, bool &rag_o, int &nragv_o) -> int {
+                nocc_o = 0; nfar_o = 0; nrmax_o = 0; rag_o = false; nragv_o = 0;
+                fv_o = 0.0;
                 if (bad) return PREP_ZONE_DONE;
                 double F[J];
                 {
                     const double fv = exp_neg(A * fabs(tnear - tj));
+                    fv_o = fv;
 #pragma unroll
                     for (int j = 0; j < J; ++j) F[j] = readlane_f64(fv, j);
                 }
@@ -1893,7 +1931,8 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     return PREP_ZONE_DONE;
                 }
                 // n_j of this lane's test site (ragged end)
-                const int nrag_v = (int)reinterpret_cast<const unsigned char *>(hp + 2)[jl];
+                nragv_o = (int)reinterpret_cast<const unsigned char *>(hp + 2)[jl];
+                nocc_o = n_occ; nfar_o = nfar_tot; nrmax_o = nrmax; rag_o = rag;
                 pos += PREP_HDR;
 
                 if (n_pair > 0) {
@@ -1993,83 +2032,80 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     }
                 }
                 pos += PREP_GUARD;
-
-                if (nfar_tot || rag) {
-                    double pk[FAR_ORDER];
-#pragma unroll
-                    for (int k = 0; k < FAR_ORDER; ++k) pk[k] = 0.0;
-                    auto fold = [&](const double m1, const double2 ma, const double2 mb, const double2 mc, const double2 md, const double R) {
-                        const double R2 = R * R, R3 = R2 * R, R4 = R2 * R2;
-                        pk[0] = fma(m1, R, pk[0]);
-                        pk[1] = fma(ma.x, R2, pk[1]);
-                        pk[2] = fma(ma.y, R3, pk[2]);
-                        pk[3] = fma(mb.x, R4, pk[3]);
-                        pk[4] = fma(mb.y, R4 * R, pk[4]);
-                        pk[5] = fma(mc.x, R4 * R2, pk[5]);
-                        pk[6] = fma(mc.y, R4 * R3, pk[6]);
-                        pk[7] = fma(md.x, R4 * R4, pk[7]);
-                    };
-                    for (int s = 0; s < n_occ; s += 2) {
-                        need();
-                        const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
-                        const bool two = s + 1 < n_occ;
-                        const ScratchEnt ua = rp[0], ub = rp[two ? PREP_MOM : 0];
-                        const double Ra = loadR(ua.ro), Rb2 = loadR(ub.ro);
-                        const double2 *qa = reinterpret_cast<const double2 *>(rp + 1);
-                        const double2 a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
-                        fold(ua.e, a0, a1, a2, a3, Ra);
-                        if (two) {
-                            const double2 *qb = reinterpret_cast<const double2 *>(rp + PREP_MOM + 1);
-                            const double2 b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3];
-                            fold(ub.e, b0, b1, b2, b3, Rb2);
-                        }
-                        pos += two ? 2 * PREP_MOM : PREP_MOM;
-                    }
-                    need();
-                    spend(2 + (int)((float)(nfar_tot + nrmax) * P.far_bits));
-#pragma unroll
-                    for (int k = 0; k < FAR_ORDER; ++k) pk[k] *= FAR_W[k];
-                    int l = 0;
-                    double rag_e = 0.0, rag_R = 0.0;
-                    if (rag) {
-                        const ScratchEnt en = ring[pos & (RING_UNITS - 1)];
-                        rag_e = en.e;
-                        rag_R = loadR(en.ro);
-                    }
-#pragma unroll
-                    for (int w = 0; w < J; w += 2) {
-                        double arg[2];
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int j = dir > 0 ? w + u : J - 1 - (w + u);
-                            if (rag) {
-                                const int nj = __builtin_amdgcn_readlane(nrag_v, j);
-                                for (; l < nj; ++l) {
-                                    const double v = rag_e * rag_R, v2 = v * v;
-                                    const ScratchEnt en = ring[(pos + l + 1) & (RING_UNITS - 1)];     // one step ahead (the guard at the end)
-                                    rag_e = en.e;
-                                    rag_R = loadR(en.ro);
-                                    pk[0] += v;
-                                    pk[1] = fma(v2, 0.5, pk[1]);
-                                    pk[2] = fma(v2 * v, 0.3333333333333333, pk[2]);
-                                }
-                            }
-                            const double f = F[j];
-                            double t = pk[FAR_ORDER - 1];
-#pragma unroll
-                            for (int k = FAR_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
-                            arg[u] = -f * t;
-                        }
-                        const int j0 = dir > 0 ? w : J - 1 - w, j1 = dir > 0 ? w + 1 : J - 2 - w;
-                        double e0, e1;
-                        exp_neg2(arg[0], arg[1], e0, e1);
-                        acc[j0] *= e0;
-                        acc[j1] *= e1;
-                        asm volatile("" : "+v"(acc[j0]), "+v"(acc[j1]));
-                    }
-                    if (rag) pos += nrmax + PREP_RAG_GUARD;
-                }
                 return base_end;
+            };
+
+            // ... second half, after both zones' near lists: fold the zone's moments, walk its ragged end, and ADD the log of
+            // the factor each test site's product has to pick up to farg (the exp is taken once for both zones)
+            auto zone_far = [&](auto dirc, double fv, int n_occ, int nfar_tot, int nrmax, bool rag, int nrag_v, double (&farg)[J]) {
+                constexpr int dir = decltype(dirc)::value;        // compile-time: farg[j] and F[j] below are registers, not indexed memory
+                if (bad || !(nfar_tot || rag)) return;
+                double F[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) F[j] = readlane_f64(fv, j);
+                double pk[FAR_ORDER];
+#pragma unroll
+                for (int k = 0; k < FAR_ORDER; ++k) pk[k] = 0.0;
+                auto fold = [&](const double m1, const double2 ma, const double2 mb, const double2 mc, const double2 md, const double R) {
+                    const double R2 = R * R, R3 = R2 * R, R4 = R2 * R2;
+                    pk[0] = fma(m1, R, pk[0]);
+                    pk[1] = fma(ma.x, R2, pk[1]);
+                    pk[2] = fma(ma.y, R3, pk[2]);
+                    pk[3] = fma(mb.x, R4, pk[3]);
+                    pk[4] = fma(mb.y, R4 * R, pk[4]);
+                    pk[5] = fma(mc.x, R4 * R2, pk[5]);
+                    pk[6] = fma(mc.y, R4 * R3, pk[6]);
+                    pk[7] = fma(md.x, R4 * R4, pk[7]);
+                };
+                for (int s = 0; s < n_occ; s += 2) {
+                    need();
+                    const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
+                    const bool two = s + 1 < n_occ;
+                    const ScratchEnt ua = rp[0], ub = rp[two ? PREP_MOM : 0];
+                    const double Ra = loadR(ua.ro), Rb2 = loadR(ub.ro);
+                    const double2 *qa = reinterpret_cast<const double2 *>(rp + 1);
+                    const double2 a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
+                    fold(ua.e, a0, a1, a2, a3, Ra);
+                    if (two) {
+                        const double2 *qb = reinterpret_cast<const double2 *>(rp + PREP_MOM + 1);
+                        const double2 b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3];
+                        fold(ub.e, b0, b1, b2, b3, Rb2);
+                    }
+                    pos += two ? 2 * PREP_MOM : PREP_MOM;
+                }
+                need();
+                spend(2 + (int)((float)(nfar_tot + nrmax) * P.far_bits));
+#pragma unroll
+                for (int k = 0; k < FAR_ORDER; ++k) pk[k] *= FAR_W[k];
+                int l = 0;
+                double rag_e = 0.0, rag_R = 0.0;
+                if (rag) {
+                    const ScratchEnt en = ring[pos & (RING_UNITS - 1)];
+                    rag_e = en.e;
+                    rag_R = loadR(en.ro);
+                }
+#pragma unroll
+                for (int w = 0; w < J; ++w) {
+                    const int j = dir > 0 ? w : J - 1 - w;
+                    if (rag) {
+                        const int nj = __builtin_amdgcn_readlane(nrag_v, j);
+                        for (; l < nj; ++l) {
+                            const double v = rag_e * rag_R, v2 = v * v;
+                            const ScratchEnt en = ring[(pos + l + 1) & (RING_UNITS - 1)];     // one step ahead (the guard at the end)
+                            rag_e = en.e;
+                            rag_R = loadR(en.ro);
+                            pk[0] += v;
+                            pk[1] = fma(v2, 0.5, pk[1]);
+                            pk[2] = fma(v2 * v, 0.3333333333333333, pk[2]);
+                        }
+                    }
+                    const double f = F[j];
+                    double t = pk[FAR_ORDER - 1];
+#pragma unroll
+                    for (int k = FAR_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
+                    farg[j] = fma(-f, t, farg[j]);              // exp_neg's argument: the factor is exp(f t)
+                }
+                if (rag) pos += nrmax + PREP_RAG_GUARD;
             };
 
             // sites between / at the test sites (and any part of the windows not covered by bulk)
@@ -2117,12 +2153,31 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
             } else {
                 for (int b = L_int; b < R_int; b += SP) generic_pass(b, +1, R_int, staged);
             }
-            // right side
-            int b = bulk_zone(+1, tL);
+            // right side, left side: near lists and whatever the zones do not cover
+            double fvR, fvL;
+            int noccR, nfarR, nrmR, nrvR, noccL, nfarL, nrmL, nrvL;
+            bool ragR, ragL;
+            int b = zone_near(+1, tL, fvR, noccR, nfarR, nrmR, ragR, nrvR);
             if (b != PREP_ZONE_DONE) { while (!generic_pass(b, +1, N, false)) b += SP; }
-            // left side
-            b = bulk_zone(-1, t0);
+            b = zone_near(-1, t0, fvL, noccL, nfarL, nrmL, ragL, nrvL);
             if (b != PREP_ZONE_DONE) { while (!generic_pass(b, -1, -1, false)) b -= SP; }
+            // the far fields of both zones: ONE exp per test site -- test sites in pairs, two interleaved exp chains, each pair
+            // final before the next one starts
+            if (!bad && (nfarR || ragR || nfarL || ragL)) {
+                double farg[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) farg[j] = 0.0;
+                zone_far(std::integral_constant<int, +1>{}, fvR, noccR, nfarR, nrmR, ragR, nrvR, farg);
+                zone_far(std::integral_constant<int, -1>{}, fvL, noccL, nfarL, nrmL, ragL, nrvL, farg);
+#pragma unroll
+                for (int w = 0; w < J; w += 2) {
+                    double e0, e1;
+                    exp_neg2(farg[w], farg[w + 1], e0, e1);
+                    acc[w] *= e0;
+                    acc[w + 1] *= e1;
+                    asm volatile("" : "+v"(acc[w]), "+v"(acc[w + 1]));
+                }
+            }
 
             renorm_all();
 #pragma unroll
@@ -2156,6 +2211,341 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 P.part_lin[o] = bL;
                 P.part_ns[o] = bE;
             }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- K2, prepared, one test site per wave
+// Sparse test sets (the reference's -s with a large step), unsorted test positions: windows share too little for groups.
+// The same split as above with J = 1: prep_solo_kernel walks each test site's window once per A -- both sides; with one
+// test site the decay separates trivially (alpha_i = E_i, F = 1), so the two sides share ONE near list and ONE set of
+// moments -- and clr_scan_solo_kernel, one wave per (test site, slice), multiplies the near list four sites per step, folds the
+// moments and takes one exp per A.  The round-2 per-site kernel did the walk (loads, exp, window test) in all eight slice
+// waves and multiplied every site of the window.
+//   blob(test site) = for iA: header (1 unit) {magic, n_near (multiple of 4), n_occ, n_far}; n_near entries (E, row offset);
+//                     4 guard entries; n_occ moment entries of 5 units
+constexpr int SOLO_MAGIC = 0x50100000;
+constexpr int SOLO_GUARD = 4;
+
+template <bool FILL>
+__global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds_p[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x / WAVE;
+    const int N = (int)P.N;
+    const int thr_len = P.thr_in_lds ? ((P.rows + 1) & ~1) : 0;
+    if (P.thr_in_lds) {
+        for (int idx = threadIdx.x; idx < P.rows; idx += blockDim.x) lds_p[idx] = P.rowthr[idx];
+        __syncthreads();
+    }
+    const int mom_len = (P.mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER;
+    double *mom = lds_p + thr_len + wave * mom_len;
+    for (int idx = lane; idx < mom_len; idx += WAVE) mom[idx] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t t = P.g_begin + (int64_t)blockIdx.x * nw + wave;       // "group" = one test site
+    if (t >= P.g_end) return;
+    auto thr_of = [&](int r) -> double {
+        double v;
+        if (P.thr_in_lds) v = lds_p[r]; else v = P.rowthr[r];
+        return v;
+    };
+    auto rank = [&](unsigned long long m) {
+        return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    };
+    const double tg = P.test_gen[t];
+    const int lo = (int)max(P.win_lo[t], (int64_t)0);
+    const int hi = (int)min(P.win_hi[t], (int64_t)N - 1);
+    const int c = (int)P.center[t], ch = (int)P.center_hi[t];     // sites in [c, ch) sit AT the test position: never in its window (v1:455)
+    int wpos = 0;
+    ScratchEnt *out = nullptr;
+    if (FILL) out = P.arena + (P.blob_prefix[t] - P.prefix_base);
+
+    for (int iA = 0; iA < P.nA; ++iA) {
+        const double A = P.A[iA];
+        const int kmom = min((int)P.kmom[iA], P.mom_slots);
+        const int hbase = wpos, nbase = hbase + 1;
+        int n_near = 0, nfar_tot = 0, pad_ro = 0;
+        bool seen = false;
+        double m1p = 0.0, m2p = 0.0;
+        for (int dir = 0; dir < 2; ++dir) {
+            // dir 0: indices max(ch, lo), +1, ... up to hi;  dir 1: min(c - 1, hi), -1, ... down to lo
+            const int base = dir == 0 ? max(ch, lo) : min(c - 1, hi);
+            int i = dir == 0 ? base + lane : base - lane;
+            double g_nx = P.genpos[min(max(i, 0), N - 1)];
+            int r_nx = (int)P.row[min(max(i, 0), N - 1)];
+            while (true) {
+                const bool valid = (i >= lo) && (i <= hi);
+                const double g = g_nx;
+                const int rraw = r_nx;
+                const int inx = dir == 0 ? i + WAVE : i - WAVE;
+                g_nx = P.genpos[min(max(inx, 0), N - 1)];
+                r_nx = (int)P.row[min(max(inx, 0), N - 1)];
+                const double zn = A * fabs(g - tg);
+                const bool in = valid && (zn <= P.zcut) && (g != tg);
+                const unsigned long long m_in = __ballot(in);
+                if (m_in != 0ull) {
+                    const double th = thr_of(rraw);
+                    const int slot = __double2loint(th) & 0xff;
+                    const bool moml = in && slot < kmom && zn >= th && nfar_tot < FAR_CAP;
+                    const bool nearl = in && !moml;
+                    const unsigned long long mm = __ballot(moml), mn = __ballot(nearl);
+                    const int nfar = __popcll(mm);
+                    if (!seen) { pad_ro = __builtin_amdgcn_readlane(rraw, __ffsll((long long)m_in) - 1) * P.rowmul; seen = true; }
+                    double Ev = 0.0;
+                    if (FILL) Ev = in ? exp_neg(zn) : 0.0;
+                    if (nfar) {
+                        if (moml) {
+                            double *mr = mom + (slot ? slot + MOM_COPIES - 1 : (lane & (MOM_COPIES - 1))) * FAR_ORDER;
+                            if (FILL) {
+                                const double d = zn - th;
+                                const double E2 = Ev * Ev;
+                                if (slot == 0) { m1p += Ev; m2p += E2; }
+                                else { atomicAdd(mr, Ev); atomicAdd(mr + 1, E2); }
+                                if (d < 7.94) {
+                                    const double E3 = E2 * Ev;
+                                    atomicAdd(mr + 2, E3);
+                                    if (d < 5.13) {
+                                        const double E4 = E2 * E2;
+                                        atomicAdd(mr + 3, E4);
+                                        if (d < 3.46) {
+                                            atomicAdd(mr + 4, E4 * Ev);
+                                            if (d < 2.36) {
+                                                atomicAdd(mr + 5, E4 * E2);
+                                                if (d < 1.58) {
+                                                    atomicAdd(mr + 6, E4 * E3);
+                                                    if (d < 0.99) atomicAdd(mr + 7, E4 * E4);
+                                                }
+                                            }
+                                        }
+                                    }
+                                }
+                            } else {
+                                mom[(slot ? slot + MOM_COPIES - 1 : 0) * FAR_ORDER] = 1.0;
+                            }
+                        }
+                        nfar_tot += nfar;
+                    }
+                    if (FILL && nearl) out[nbase + n_near + rank(mn)] = ScratchEnt{Ev, rraw * P.rowmul, 0};
+                    n_near += __popcll(mn);
+                }
+                // the walk ends where the window does: its index bound, or the first site past the cut-off (positions are sorted)
+                if (__ballot(valid && zn > P.zcut) != 0ull || __ballot(valid) != ~0ull) break;
+                i = inx;
+            }
+        }
+        const int n_near_pad = (n_near + 3) & ~3;
+        if (FILL) {
+            if (lane < n_near_pad - n_near + SOLO_GUARD) out[nbase + n_near + lane] = ScratchEnt{0.0, pad_ro, 0};
+        }
+        wpos = nbase + n_near_pad + SOLO_GUARD;
+        int n_occ = 0;
+        if (nfar_tot) {
+            __builtin_amdgcn_wave_barrier();
+            {
+                double x = 0.0;
+                if (lane < MOM_COPIES * FAR_ORDER) {
+                    x = mom[lane];
+                    mom[lane] = 0.0;
+                }
+                if (FILL) {
+                    double y1 = m1p, y2 = m2p;
+#pragma unroll
+                    for (int off = 1; off < FAR_ORDER; off <<= 1) {
+                        y1 += __shfl_xor(y1, off);
+                        y2 += __shfl_xor(y2, off);
+                    }
+                    const int k8 = lane & (FAR_ORDER - 1);
+                    x += k8 == 0 ? y1 : k8 == 1 ? y2 : 0.0;
+                }
+#pragma unroll
+                for (int cc = MOM_COPIES / 2; cc >= 1; cc >>= 1) x += __shfl_down(x, cc * FAR_ORDER);
+                const double m0 = readlane_f64(x, 0);
+                if (m0 != 0.0) {
+                    if (FILL) {
+                        double m[FAR_ORDER];
+#pragma unroll
+                        for (int k = 0; k < FAR_ORDER; ++k) m[k] = readlane_f64(x, k);
+                        if (lane == 0) {
+                            ScratchEnt *o = out + wpos;
+                            o[0] = ScratchEnt{m[0], P.row_of_slot[0] * P.rowmul, 0};
+                            double2 *o2 = reinterpret_cast<double2 *>(o + 1);
+                            o2[0] = double2{m[1], m[2]};
+                            o2[1] = double2{m[3], m[4]};
+                            o2[2] = double2{m[5], m[6]};
+                            o2[3] = double2{m[7], 0.0};
+                        }
+                    }
+                    n_occ = 1;
+                }
+            }
+            for (int s0 = 1; s0 < kmom; s0 += WAVE) {
+                const int s = s0 + lane;
+                double m[FAR_ORDER];
+#pragma unroll
+                for (int k = 0; k < FAR_ORDER; ++k) m[k] = 0.0;
+                if (s < kmom) {
+                    double *ms = mom + (s + MOM_COPIES - 1) * FAR_ORDER;
+#pragma unroll
+                    for (int k = 0; k < FAR_ORDER; ++k) { m[k] = ms[k]; ms[k] = 0.0; }
+                }
+                const bool occ = m[0] != 0.0;
+                const unsigned long long mo = __ballot(occ);
+                if (FILL && occ) {
+                    ScratchEnt *o = out + wpos + PREP_MOM * (n_occ + rank(mo));
+                    o[0] = ScratchEnt{m[0], P.row_of_slot[s] * P.rowmul, 0};
+                    double2 *o2 = reinterpret_cast<double2 *>(o + 1);
+                    o2[0] = double2{m[1], m[2]};
+                    o2[1] = double2{m[3], m[4]};
+                    o2[2] = double2{m[5], m[6]};
+                    o2[3] = double2{m[7], 0.0};
+                }
+                n_occ += __popcll(mo);
+            }
+            __builtin_amdgcn_wave_barrier();
+            wpos += PREP_MOM * n_occ;
+        }
+        if (FILL && lane == 0) *reinterpret_cast<int4 *>(out + hbase) = int4{SOLO_MAGIC, n_near_pad, n_occ, nfar_tot};
+    }
+    const int units = (wpos + 3) & ~3;
+    if (!FILL) {
+        if (lane == 0) P.blob_units[t] = units;
+    } else {
+        if (lane == 0 && (int64_t)units != P.blob_prefix[t + 1] - P.blob_prefix[t]) atomicOr(P.status, 1);
+    }
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(SITE_THREADS) void clr_scan_solo_kernel(ScanParams P, PrepView V) {
+    extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then one ring per wave
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = blockDim.x / WAVE;
+    const int slice = blockIdx.x % P.nslices;   // blocks b, b+8 share an XCD: one R slice per L2
+    const int64_t chunk = blockIdx.x / P.nslices;
+    const int p = slice * WAVE + lane;
+    if (USE_LDS) {
+        const int total = P.rows * WAVE;
+        for (int idx = threadIdx.x; idx < total; idx += blockDim.x)
+            lds_R[idx] = P.Rt[(size_t)(idx >> 6) * P.NP + slice * WAVE + (idx & 63)];
+    }
+    const char *Rb = reinterpret_cast<const char *>(P.Rt + slice * WAVE);
+    const unsigned lane8 = (unsigned)lane * 8u;
+    auto loadR = [&](int rowoff) -> double {
+        return USE_LDS ? lds_R[rowoff + lane] : *reinterpret_cast<const double *>(Rb + ((unsigned)rowoff * 8u + lane8));
+    };
+    constexpr int WAVE_UNITS = RING_UNITS + RING_MIRROR;
+    ScratchEnt *ring = reinterpret_cast<ScratchEnt *>(lds_R + (USE_LDS ? P.rows * WAVE : 0)) + wave * WAVE_UNITS;
+    double2 *ring2 = reinterpret_cast<double2 *>(ring);
+    for (int idx = lane; idx < WAVE_UNITS; idx += WAVE) ring[idx] = ScratchEnt{0.0, 0, 0};
+    if (USE_LDS) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+
+    const int64_t t_begin = chunk * P.sites_per_block;
+    const int64_t t_end = min(t_begin + (int64_t)P.sites_per_block, P.M);
+    for (int64_t t = t_begin + wave; t < t_end; t += nw) {
+        const double2 *src = reinterpret_cast<const double2 *>(V.arena + (V.blob_prefix[V.grp_base + t] - V.prefix_base));
+        int pos = 0, staged_u = 0;
+        double nx_a, nx_b;
+        {
+            const double2 q = src[lane];
+            nx_a = q.x; nx_b = q.y;
+        }
+        auto stage = [&]() {
+            const int slot = (staged_u >> 6) & 3;
+            ring2[slot * WAVE + lane] = double2{nx_a, nx_b};
+            if (slot == 0 && lane < RING_MIRROR) ring2[RING_UNITS + lane] = double2{nx_a, nx_b};
+            staged_u += WAVE;
+            const double2 q = src[staged_u + lane];
+            nx_a = q.x; nx_b = q.y;
+            __builtin_amdgcn_wave_barrier();
+        };
+        auto need = [&]() {
+            if (pos + 80 > staged_u) stage();
+        };
+        stage();
+        stage();
+        bool bad = false;
+        double bestM = 1.0;
+        int bestEc = 131072, bestA = -1;
+        for (int iA = 0; iA < P.nA && !bad; ++iA) {
+            need();
+            const int4 h = *reinterpret_cast<const int4 *>(ring + (pos & (RING_UNITS - 1)));
+            const int magic = __builtin_amdgcn_readfirstlane(h.x), n_near = __builtin_amdgcn_readfirstlane(h.y);
+            const int n_occ = __builtin_amdgcn_readfirstlane(h.z), nfar = __builtin_amdgcn_readfirstlane(h.w);
+            if (magic != SOLO_MAGIC || n_near < 0 || (n_near & 3) || n_near > (int)P.N + 8 || n_occ < 0 || n_occ > MOM_SLOTS) { bad = true; break; }
+            pos += 1;
+            double acc = 1.0;
+            int E = 0, since = 0;
+            for (int l = 0; l < n_near; l += 4) {
+                need();
+                const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
+                double f[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const ScratchEnt en = rp[u];                    // uniform address: LDS broadcast
+                    f[u] = fma(en.e, loadR(en.ro), 1.0);
+                }
+                acc *= (f[0] * f[1]) * (f[2] * f[3]);
+                since += 4;
+                if (since + 4 > P.renorm_every) {
+                    renorm(acc, E);
+                    since = 0;
+                }
+                pos += 4;
+            }
+            pos += SOLO_GUARD;
+            if (nfar) {
+                // fold the moments (both sides of the window at once: F = 1) and multiply by exp(sum_k -+ w_k p_k)
+                double pk[FAR_ORDER];
+#pragma unroll
+                for (int k = 0; k < FAR_ORDER; ++k) pk[k] = 0.0;
+                for (int s = 0; s < n_occ; ++s) {
+                    need();
+                    const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
+                    const ScratchEnt ua = rp[0];
+                    const double R = loadR(ua.ro);
+                    const double2 *qa = reinterpret_cast<const double2 *>(rp + 1);
+                    const double2 a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
+                    const double R2 = R * R, R3 = R2 * R, R4 = R2 * R2;
+                    pk[0] = fma(ua.e, R, pk[0]);
+                    pk[1] = fma(a0.x, R2, pk[1]);
+                    pk[2] = fma(a0.y, R3, pk[2]);
+                    pk[3] = fma(a1.x, R4, pk[3]);
+                    pk[4] = fma(a1.y, R4 * R, pk[4]);
+                    pk[5] = fma(a2.x, R4 * R2, pk[5]);
+                    pk[6] = fma(a2.y, R4 * R3, pk[6]);
+                    pk[7] = fma(a3.x, R4 * R4, pk[7]);
+                    pos += PREP_MOM;
+                }
+                double tsum = pk[FAR_ORDER - 1] * FAR_W[FAR_ORDER - 1];
+#pragma unroll
+                for (int k = FAR_ORDER - 2; k >= 0; --k) tsum = fma(pk[k], FAR_W[k], -tsum);      // w1 p1 - (w2 p2 - (w3 p3 - ...))
+                renorm(acc, E);                      // |tsum| <= FAR_CAP * 0.05 * 1.03 < 422: 2^609 on top of [1, 2) is safe
+                since = 0;
+                acc *= exp_neg(-tsum);
+            }
+            renorm(acc, E);
+            const int ec = min(max(E, -131071), 131071) + 131072;
+            if (((ec > bestEc) || (ec == bestEc && acc > bestM)) && p < P.npairs) {       // strict '>' (v1:501); iA ascending
+                bestM = acc;
+                bestEc = ec;
+                bestA = iA;
+            }
+        }
+        if (bad && lane == 0) atomicOr(V.status, 2);
+        int bE = bestEc;
+        int bL = (bestA < 0 || bad) ? 0x7fffffff : bestA * P.npairs + p;
+        for (int off = 32; off > 0; off >>= 1) {
+            const int oE = __shfl_xor(bE, off);
+            const double oM = __shfl_xor(bestM, off);
+            const int oL = __shfl_xor(bL, off);
+            if (oE > bE || (oE == bE && (oM > bestM || (oM == bestM && oL < bL)))) { bE = oE; bestM = oM; bL = oL; }
+        }
+        if (lane == 0) {
+            const size_t o = (size_t)slice * P.M + t;
+            P.part_T[o] = bestM;
+            P.part_lin[o] = bL;
+            P.part_ns[o] = bE;
         }
     }
 }
@@ -2350,7 +2740,7 @@ struct ScanPlan {
     // prepared pipeline (mode 4): the per-group kernel's two forms and its launch shape
     const void *prep_count = nullptr, *prep_fill = nullptr;
     size_t prep_lds = 0;
-    int thr_in_lds = 0;
+    int thr_in_lds = 0, prep_threads = PREP_THREADS;
 };
 
 // One chromosome of a context (a "slot"): its site arrays, its test sites, their results and the scan plan made for them.
@@ -2961,8 +3351,12 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
     //           3 -> J=8, 4 -> J=4 (same form); 10/11 -> J=16/8 without the power sums (exact products);
     //           8/9 -> J=16/8 pairs only; 5/6/7 -> J=16/8/4 readlane single-site loop; 1, 2 -> per-site kernel
     const int v = c->variant;
-    const bool prepared = can_group && (v == 0 || (v >= 13 && v <= 15)) && FAR_ORDER == 8 && !diag_env("BMX_FAR_EPS");
-    if (can_group) {
+    const bool prep_ok = FAR_ORDER == 8 && !diag_env("BMX_FAR_EPS");
+    // one test site per wave, prepared (mode 5): sparse or unsorted test sites (variant 0), or on request (variant 16)
+    const int64_t solo_gap = diag_env("BMX_SOLO_GAP") ? atoll(diag_env("BMX_SOLO_GAP")) : SOLO_GAP;
+    const bool solo = prep_ok && !P.wide_tab && s->N < 0x7fffffffLL && (v == 16 || (v == 0 && (!can_group || s->test_gap > solo_gap)));
+    const bool prepared = !solo && can_group && (v == 0 || (v >= 13 && v <= 15)) && prep_ok;
+    if (can_group && !solo) {
         J = (v == 0 || v == 12 || v == 5 || v == 8 || v == 10 || v == 13) ? 16 : (v == 3 || v == 6 || v == 9 || v == 11 || v == 14) ? 8
             : (v == 4 || v == 7 || v == 15) ? 4 : 0;
         if (v == 0 || v == 12) J = s->test_gap <= 3 ? 16 : s->test_gap <= 28 ? 8 : 4;
@@ -2976,16 +3370,17 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
     // scratch list and the moments; both the sites between the test sites; the slice's per-row max |R| only the latter
     int mom_slots = MOM_SLOTS_LDS;
     auto wave_bytes = [&](int slots) {
+        if (solo) return (size_t)(RING_UNITS + RING_MIRROR) * sizeof(ScratchEnt);
         if (prepared) return (size_t)(RING_UNITS + RING_MIRROR + AUX_UNITS) * sizeof(ScratchEnt) + (size_t)MID_CAP * 12;
         return SCR_CAP * sizeof(ScratchEnt) + (size_t)(slots + MOM_COPIES - 1 + 3) * FAR_ORDER * sizeof(double) + (size_t)MID_CAP * 12;
     };
-    const size_t lds_rm = prepared ? 0 : (size_t)((c->rows + 1) & ~1) * sizeof(double);
-    auto lds_need = [&](int slots) { return lds + lds_rm + (size_t)(SCAN_THREADS_MAX / WAVE) * wave_bytes(slots); };
+    const size_t lds_rm = (prepared || solo) ? 0 : (size_t)((c->rows + 1) & ~1) * sizeof(double);
+    auto lds_need = [&](int slots) { return lds + lds_rm + (size_t)((solo ? SITE_THREADS : SCAN_THREADS_MAX) / WAVE) * wave_bytes(slots); };
     // moment slots: as many (64, 32, 16, 8, 0) as leave the R slice in LDS; when the table is too large for LDS anyway
     // (many sample sizes: the sites spread over many rows), all MOM_SLOTS.  (The prepared pipeline's moments live in
     // prep_kernel's LDS: 64 slots with the table in LDS, all of them otherwise -- the same rule, so that both forms
     // classify alike.)
-    while (!prepared && mom_slots >= 8 && lds_need(mom_slots) > (size_t)LDS_LIMIT_BYTES) mom_slots /= 2;
+    while (!prepared && !solo && mom_slots >= 8 && lds_need(mom_slots) > (size_t)LDS_LIMIT_BYTES) mom_slots /= 2;
     if (mom_slots < 8) mom_slots = 0;
     const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES && !diag_env("BMX_NO_LDS");   // BMX_NO_LDS: R from L2 (A/B runs)
     if (!fits || c->variant == 1) mom_slots = MOM_SLOTS;
@@ -2998,13 +3393,14 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
 #define PICK(K) (use_lds ? (const void *)K<true> : (const void *)K<false>)
     // inner-loop form: 0 readlane / one site per step; 1 LDS broadcast + pairs; 2 = 1 + four sites per
     // step where alpha <= 1/2; 3 = 2 + power sums where alpha*max|R| <= far_eps; 4 = 3 with the per-group work prepared
-    const int mode = prepared ? 4 : (v >= 5 && v <= 7) ? 0 : (v >= 8 && v <= 9) ? 1 : (v >= 10 && v <= 11) ? 2 : 3;
+    const int mode = solo ? 5 : prepared ? 4 : (v >= 5 && v <= 7) ? 0 : (v >= 8 && v <= 9) ? 1 : (v >= 10 && v <= 11) ? 2 : 3;
 #define GP2(JJ, MM) (use_lds ? (const void *)clr_scan_grouped_kernel<JJ, true, MM> : (const void *)clr_scan_grouped_kernel<JJ, false, MM>)
 #define GP4(JJ) (use_lds ? (const void *)clr_scan_prepared_kernel<JJ, true> : (const void *)clr_scan_prepared_kernel<JJ, false>)
 #define GPICK(JJ) (mode == 4 ? GP4(JJ) : mode == 3 ? GP2(JJ, 3) : mode == 2 ? GP2(JJ, 2) : mode == 1 ? GP2(JJ, 1) : GP2(JJ, 0))
     if (J == 8) fn = GPICK(8);
     else if (J == 16) fn = GPICK(16);
     else if (J == 4) fn = GPICK(4);
+    else if (solo) fn = PICK(clr_scan_solo_kernel);
     else fn = PICK(clr_scan_kernel);
 #undef GP2
 #undef GP4
@@ -3019,29 +3415,37 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
         lds_bytes = (use_lds ? lds + lds_rm : 0) + (size_t)(threads / WAVE) * wave_bytes(mom_slots);
         spb *= 2;
     }
-    if (!J) {       // per-site kernel: 16 waves, the R slice (if it fits) + 1 KB of scratch list per wave
+    if (!J) {       // per-site kernels: 16 waves, the R slice (if it fits) + 1 KB of scratch list (solo: 4.3 KB of ring) per wave
         threads = SITE_THREADS;
-        lds_bytes = (use_lds ? lds : 0) + (size_t)(threads / WAVE) * SITE_SCR * sizeof(ScratchEnt);
+        lds_bytes = (use_lds ? lds : 0) + (size_t)(threads / WAVE) * (solo ? wave_bytes(0) : SITE_SCR * sizeof(ScratchEnt));
     }
     if (lds_bytes > (size_t)LDS_LIMIT_BYTES) return fail(BMX_E_LIMIT, "LDS budget exceeded");
     if (lds_bytes) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     P.sites_per_block = spb;
-    pl.fn = fn; pl.J = J; pl.threads = threads; pl.lds_bytes = lds_bytes; pl.spb = spb; pl.use_lds = use_lds; pl.mode = J ? mode : -1;
+    pl.fn = fn; pl.J = solo ? 1 : J; pl.threads = threads; pl.lds_bytes = lds_bytes; pl.spb = spb; pl.use_lds = use_lds;
+    pl.mode = solo ? 5 : J ? mode : -1;
     // test sites per launch: keeps the per-slice winners (16 B x slices per test site) within ~512 MB and the grid
     // within 2^31 workgroups; a multiple of the workgroup's share, so ranges cut the test sites where workgroups do
     int64_t range = std::max<int64_t>((int64_t)(512u << 20) / (16 * (int64_t)c->nslices), spb);
     range = std::min<int64_t>(range, (int64_t)0x7fffff00LL / c->nslices * spb);
     range = std::max<int64_t>(range / spb, 1) * spb;
     pl.range = range;
-    if (prepared) {
+    if (prepared || solo) {
         pl.thr_in_lds = c->rows <= PREP_THR_LDS_MAX ? 1 : 0;
         const int pm = use_lds ? MOM_SLOTS_LDS : MOM_SLOTS;      // the moment slots of prep_kernel (see above)
         P.mom_slots = pm;
+        pl.prep_threads = (pm > MOM_SLOTS_LDS && !solo) ? PREP_THREADS / 2 : PREP_THREADS;     // two moment arrays per wave: 34 KB with all 254 slots
         pl.prep_lds = ((pl.thr_in_lds ? (size_t)((c->rows + 1) & ~1) : 0) +
-                       (size_t)(PREP_THREADS / WAVE) * ((size_t)(pm + MOM_COPIES - 1 + 3) * FAR_ORDER + WAVE)) * sizeof(double);
+                       (size_t)(pl.prep_threads / WAVE) * (solo ? (size_t)(pm + MOM_COPIES - 1 + 3) * FAR_ORDER
+                                                                 : 2 * (size_t)(pm + MOM_COPIES - 1 + 3) * FAR_ORDER + WAVE)) * sizeof(double);
 #define PP(JJ, FF) (const void *)prep_kernel<JJ, FF>
-        pl.prep_count = J == 16 ? PP(16, false) : J == 8 ? PP(8, false) : PP(4, false);
-        pl.prep_fill = J == 16 ? PP(16, true) : J == 8 ? PP(8, true) : PP(4, true);
+        if (solo) {
+            pl.prep_count = (const void *)prep_solo_kernel<false>;
+            pl.prep_fill = (const void *)prep_solo_kernel<true>;
+        } else {
+            pl.prep_count = J == 16 ? PP(16, false) : J == 8 ? PP(8, false) : PP(4, false);
+            pl.prep_fill = J == 16 ? PP(16, true) : J == 8 ? PP(8, true) : PP(4, true);
+        }
 #undef PP
         if (pl.prep_lds > (size_t)LDS_LIMIT_BYTES) return fail(BMX_E_LIMIT, "LDS budget of the preparation kernel exceeded");
         HIP_TRY(hipFuncSetAttribute(pl.prep_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prep_lds));
@@ -3071,16 +3475,16 @@ PrepParams prep_params(bmx_ctx *c, ChromSlot *s, const ScanPlan &pl) {
 // sizes, and the launch ranges -- cut where the per-slice winner arrays (pl.range) or the arena would overflow.
 int ensure_prep(bmx_ctx *c, ChromSlot *s) {
     ScanPlan &pl = s->plan;
-    if (pl.mode != 4 || s->prep_ok) return BMX_OK;
+    if (pl.mode < 4 || s->prep_ok) return BMX_OK;
     const int J = pl.J;
     const int64_t ngroups = (s->M + J - 1) / J;
     HIP_TRY(s->blob_units.ensure((size_t)ngroups));
     HIP_TRY(s->blob_prefix.ensure((size_t)ngroups + 1));
     PrepParams Q = prep_params(c, s, pl);
     Q.g_begin = 0; Q.g_end = ngroups;
-    const int gpw = PREP_THREADS / WAVE;
+    const int gpw = pl.prep_threads / WAVE;
     void *kargs[] = {&Q};
-    HIP_TRY(hipLaunchKernel(pl.prep_count, dim3((unsigned)((ngroups + gpw - 1) / gpw)), dim3(PREP_THREADS), kargs, pl.prep_lds, c->stream));
+    HIP_TRY(hipLaunchKernel(pl.prep_count, dim3((unsigned)((ngroups + gpw - 1) / gpw)), dim3(pl.prep_threads), kargs, pl.prep_lds, c->stream));
     hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t *)s->blob_units.p, ngroups, s->blob_prefix.p);
     HIP_TRY(hipGetLastError());
     std::vector<int64_t> pre((size_t)ngroups + 1);
@@ -3135,15 +3539,16 @@ int launch_range(bmx_ctx *c, ChromSlot *s, ScanPlan &pl, int64_t off, int64_t cn
     P.test_gen = s->test_gen.p + off; P.win_lo = s->win_lo.p + off; P.win_hi = s->win_hi.p + off;
     P.center = s->center.p + off; P.center_hi = s->center_hi.p + off; P.M = cnt;
     P.part_T = c->part_T.p; P.part_lin = c->part_lin.p; P.part_ns = c->part_ns.p;
-    const int64_t blocks = (cnt + pl.spb - 1) / pl.spb * c->nslices;
+    int64_t blocks = (cnt + pl.spb - 1) / pl.spb * c->nslices;
+    if (pr && BMX_XCD_MAP && pl.mode == 4) blocks = ((cnt + pl.spb - 1) / pl.spb + 7) / 8 * 8 * c->nslices;     // chunks padded to whole XCD rounds
     if (pr) {
         // the range's blobs: filled by the per-group kernel, then consumed by one wave per (group, slice)
         if ((size_t)pr->units + 4 * WAVE > c->arena.cap) HIP_TRY(c->arena.ensure((size_t)pr->units + 4 * WAVE));
         PrepParams Q = prep_params(c, s, pl);
         Q.g_begin = pr->g0; Q.g_end = pr->g0 + pr->ng; Q.prefix_base = pr->pbase;
-        const int gpw = PREP_THREADS / WAVE;
+        const int gpw = pl.prep_threads / WAVE;
         void *qargs[] = {&Q};
-        HIP_TRY(hipLaunchKernel(pl.prep_fill, dim3((unsigned)((pr->ng + gpw - 1) / gpw)), dim3(PREP_THREADS), qargs, pl.prep_lds, c->stream));
+        HIP_TRY(hipLaunchKernel(pl.prep_fill, dim3((unsigned)((pr->ng + gpw - 1) / gpw)), dim3(pl.prep_threads), qargs, pl.prep_lds, c->stream));
         PrepView V;
         V.arena = c->arena.p; V.blob_prefix = s->blob_prefix.p; V.prefix_base = pr->pbase; V.grp_base = pr->g0; V.status = c->d_status;
         void *kargs[] = {&P, &V};
@@ -3169,7 +3574,7 @@ int scan_ranges(bmx_ctx *c, ChromSlot *s, std::vector<PrepRange> &out) {
     int rc = ensure_plan(c, s);
     if (rc) return rc;
     out.clear();
-    if (s->plan.mode == 4) { out = s->ranges; return BMX_OK; }
+    if (s->plan.mode >= 4) { out = s->ranges; return BMX_OK; }
     for (int64_t off = 0; off < s->M; off += s->plan.range)
         out.push_back(PrepRange{off, std::min(s->plan.range, s->M - off), 0, 0, 0, 0});
     return BMX_OK;
@@ -3200,7 +3605,7 @@ int bmx_ctx_scan(bmx_ctx *c) {
     if (rc) return rc;
     HIP_TRY(hipEventRecord(s->ev0, c->stream));
     for (const PrepRange &r : rs)
-        if ((rc = launch_range(c, s, s->plan, r.off, r.cnt, s->plan.mode == 4 ? &r : nullptr))) return rc;
+        if ((rc = launch_range(c, s, s->plan, r.off, r.cnt, s->plan.mode >= 4 ? &r : nullptr))) return rc;
     HIP_TRY(hipEventRecord(s->ev1, c->stream));
     s->timed = true;
     return BMX_OK;
@@ -3221,7 +3626,7 @@ int bmx_ctx_plan(bmx_ctx *c, int32_t *J, int32_t *use_lds, int32_t *mode, int64_
     if (mode) *mode = s->plan.mode;
     if (stream_bytes) {
         int64_t u = 0;
-        if (s->plan.mode == 4) for (const PrepRange &r : s->ranges) u += r.units;
+        if (s->plan.mode >= 4) for (const PrepRange &r : s->ranges) u += r.units;
         *stream_bytes = u * (int64_t)sizeof(ScratchEnt);
     }
     return BMX_OK;
@@ -3401,7 +3806,7 @@ extern "C" int bmx_ctx_scan_write(bmx_ctx *c, const char *path, const int64_t *p
     // chunks: the prepared pipeline's launch ranges as they are (their blobs were sized per range); otherwise `chunk` test
     // sites at a time (0: 65536; whole workgroups, which keeps every result bit-identical to bmx_ctx_scan)
     std::vector<PrepRange> chunks;
-    if (pl.mode == 4) {
+    if (pl.mode >= 4) {
         // a prepared range is cut further into chunks of whole workgroups: each chunk's groups are a sub-range of the
         // range's blobs (same arena, same prefix base), so nothing has to be re-planned
         if (chunk <= 0) chunk = 65536;
@@ -3511,7 +3916,7 @@ extern "C" int bmx_ctx_scan_write(bmx_ctx *c, const char *path, const int64_t *p
             if (werr) { stopped = true; break; }
             slot_free[slot] = false;
         }
-        if (pl.mode == 4) {
+        if (pl.mode >= 4) {
             // the chunk's groups within its range: fill + consume exactly those
             PrepRange sub = q;
             sub.g0 = q.off / pl.J;

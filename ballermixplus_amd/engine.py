@@ -122,7 +122,9 @@ class Context:
         sb = C.c_int64()
         _lib.check(self._L.bmx_ctx_plan(self._h, C.byref(J), C.byref(ul), C.byref(mode), C.byref(sb)))
         lds = 'true' if ul.value else 'false'
-        if mode.value == 4:
+        if mode.value == 5:
+            name = 'clr_scan_solo_kernel<%s>' % lds
+        elif mode.value == 4:
             name = 'clr_scan_prepared_kernel<%d,%s>' % (J.value, lds)
         elif mode.value >= 0:
             name = 'clr_scan_grouped_kernel<%d,%s,%d>' % (J.value, lds, mode.value)

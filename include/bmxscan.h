@@ -192,7 +192,8 @@ int bmx_ctx_slot_count(bmx_ctx *c);
 int bmx_ctx_pack_records(bmx_ctx *c, void *dst, int64_t cap, int32_t dst_on_device, int64_t *n_out);
 /* What the scan of the selected slot launches (valid once its test sites are set): *J = test sites per wave-group (0: one
  * test site per wave), *use_lds = 1 if the R slice is read from LDS, *mode = 4 prepared pipeline (prep_kernel +
- * clr_scan_prepared_kernel), 0..3 the round-2 grouped forms, -1 the per-site kernel; *stream_bytes = bytes of the prepared
+ * clr_scan_prepared_kernel), 5 prepared pipeline with one test site per wave (prep_solo_kernel + clr_scan_solo_kernel, *J = 1:
+ * sparse or unsorted test sites), 0..3 the round-2 grouped forms, -1 the round-2 per-site kernel; *stream_bytes = bytes of the prepared
  * per-group streams of all test sites (0 otherwise).  Any pointer may be NULL. */
 int bmx_ctx_plan(bmx_ctx *c, int32_t *J, int32_t *use_lds, int32_t *mode, int64_t *stream_bytes);
 

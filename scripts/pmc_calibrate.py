@@ -1,13 +1,28 @@
 """Turns the counter CSVs of scripts/pmc_collect.sh into the per-evaluation / per-window figures bench.py's roofline uses.
-    python scripts/pmc_calibrate.py <tag> <dir>     -> prints a summary and the JSON entry for profiles/r02_pmc_calibration.json
-All counters are summed over the dispatches of the scan kernel in one bench step; evaluations and windows of that step come
-from the bench line of the same process (evals_per_step: sum over test sites of |x| |alpha| sum_A W_A)."""
+    python scripts/pmc_calibrate.py <tag> <dir>     -> prints a summary and the JSON entry for profiles/r03_pmc_calibration.json
+All counters are summed over the dispatches of the scan kernels (the per-group preparation kernel prep_kernel<J,true> and
+the pair-parallel kernel clr_scan_*) in one bench step -- the counting pass prep_kernel<J,false> runs when the test sites
+are set, outside the step, and is listed separately; evaluations and windows of that step come from the bench line of the
+same process (evals_per_step: sum over test sites of |x| |alpha| sum_A W_A)."""
 import collections, csv, glob, json, os, sys
 
 tag, root = sys.argv[1], sys.argv[2]
 tot = collections.defaultdict(float)
+per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))
 ndisp = {}
 dur = {}
+dur_k = collections.defaultdict(lambda: collections.defaultdict(float))
+
+
+def family(name):
+    """'scan', 'prep' (fill pass), 'count' (counting pass, outside the step) or None"""
+    if 'clr_scan' in name:
+        return 'scan'
+    if 'prep_kernel' in name:
+        return 'count' if 'false>' in name.replace(' ', '') else 'prep'
+    return None
+
+
 for p in sorted(glob.glob(os.path.join(root, '*'))):
     if not os.path.isdir(p):
         continue
@@ -15,7 +30,11 @@ for p in sorted(glob.glob(os.path.join(root, '*'))):
     for f in glob.glob(os.path.join(p, '**', '*counter_collection.csv'), recursive=True):
         seen = set()
         for r in csv.DictReader(open(f)):
-            if 'clr_scan' not in r['Kernel_Name']:
+            fam = family(r['Kernel_Name'])
+            if fam is None:
+                continue
+            per_kernel[fam][r['Counter_Name']] += float(r['Counter_Value'])
+            if fam == 'count':
                 continue
             tot[r['Counter_Name']] += float(r['Counter_Value'])
             seen.add(r['Dispatch_Id'])
@@ -23,8 +42,13 @@ for p in sorted(glob.glob(os.path.join(root, '*'))):
     for f in glob.glob(os.path.join(p, '**', '*kernel_trace.csv'), recursive=True):
         d = 0.0
         for r in csv.DictReader(open(f)):
-            if 'clr_scan' in r['Kernel_Name']:
-                d += (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-6
+            fam = family(r['Kernel_Name'])
+            if fam is None:
+                continue
+            t = (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-6
+            dur_k[name][fam] += t
+            if fam != 'count':
+                d += t
         dur[name] = d
 bench = None
 for p in sorted(glob.glob(os.path.join(root, '*.json'))):
@@ -41,7 +65,9 @@ windows = bench['config']['windows_per_step']
 print('%s: %d scan-kernel dispatches per pass %s, %.4g evaluations, %d windows; profiled kernel time per pass (ms): %s'
       % (tag, max(ndisp.values() or [0]), dict(ndisp), evals, windows, {k: round(v, 1) for k, v in dur.items()}))
 for k in sorted(tot):
-    print('   %-28s %.6g' % (k, tot[k]))
+    print('   %-28s %.6g   (scan kernel %.6g, preparation kernel %.6g; counting pass, outside the step: %.6g)'
+          % (k, tot[k], per_kernel['scan'].get(k, 0.0), per_kernel['prep'].get(k, 0.0), per_kernel['count'].get(k, 0.0)))
+print('   kernel time per pass (ms) by kernel:', {k: {f: round(v, 1) for f, v in d.items()} for k, d in dur_k.items()})
 g = lambda k: tot.get(k, 0.0)
 valu = g('SQ_INSTS_VALU')
 fma, mul, add, trans = g('SQ_INSTS_VALU_FMA_F64'), g('SQ_INSTS_VALU_MUL_F64'), g('SQ_INSTS_VALU_ADD_F64'), g('SQ_INSTS_VALU_TRANS_F64')
@@ -67,8 +93,10 @@ entry = {
     'hbm_read_bytes_per_window': g('FETCH_SIZE') * 1024.0 * 2.0 / windows,
     'hbm_write_bytes_per_window': g('WRITE_SIZE') * 1024.0 / windows,
     'windows': windows, 'evals': evals, 'dispatches': max(ndisp.values() or [0]),
+    'kernel': bench['roofline']['kernel'], 'build_id': bench['config'].get('library_build'),
+    'valu_share_of_preparation_kernel': per_kernel['prep'].get('SQ_INSTS_VALU', 0.0) / valu if valu else None,
     'kernel_ms_profiled': dur,
     'source': 'rocprofv3 --pmc passes A-E of `python3 bench.py %s --steps 1 --warmup 0 --no-cpu-baseline` (scripts/pmc_collect.sh %s), '
-              'profiles/r02_pmc_%s_summary.txt' % (' '.join(sys.argv[3:]) or '--config ' + tag.strip('c'), tag, tag),
+              'profiles/r03_pmc_%s_summary.txt' % (' '.join(sys.argv[3:]) or '--config ' + tag.strip('c'), tag, tag),
 }
 print(json.dumps({('config' + tag.strip('c')): entry}, indent=1))

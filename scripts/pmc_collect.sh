@@ -2,11 +2,11 @@
 # Collects the rocprofv3 evidence behind bench.py's roofline (run on the GPU box, from the repo root):
 #   bash scripts/pmc_collect.sh <tag> <bench args...>      e.g.  bash scripts/pmc_collect.sh c3 --config 3
 # One process per counter group (the SQ block has 8 slots, FETCH_SIZE and WRITE_SIZE do not fit one TCC pass), each with
-# --kernel-trace so that the dispatch list comes with it; the program sits directly behind `--`.  Output: gpurun_out/r02/<tag>/.
+# --kernel-trace so that the dispatch list comes with it; the program sits directly behind `--`.  Output: gpurun_out/r03/<tag>/.
 set -u
 TAG=$1; shift
 R=$(pwd)
-OUT=$R/gpurun_out/r02/$TAG
+OUT=$R/gpurun_out/r03/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$* --steps 1 --warmup 0 --no-cpu-baseline"

@@ -332,7 +332,7 @@ def test_multiple_sample_sizes_and_large_tables(sizes, label):
 
 
 # kernel variants exercised by the randomised scenarios (bmx_ctx_set_variant); overridable for fuzz runs
-RANDOMISED_VARIANTS = tuple(int(v) for v in os.environ.get('BMX_TEST_VARIANTS', '0,2,12,14,15,3,8,10').split(','))
+RANDOMISED_VARIANTS = tuple(int(v) for v in os.environ.get('BMX_TEST_VARIANTS', '0,2,16,12,14,15,3,8,10').split(','))
 
 
 @pytest.mark.parametrize('seed', list(range(15)))

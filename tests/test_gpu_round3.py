@@ -27,8 +27,8 @@ def _synth_model(n=100, chroms=((1, 200000),), bal=False):
 
 
 def test_plan_names_the_kernel_that_runs():
-    """bmx_ctx_plan: dense test sites -> prepared pipeline, J = 16, table in LDS; every 40th SNP -> J = 4; every 200th -> the
-    per-site kernel; variant 12 -> the round-2 grouped kernel; 41 sample sizes -> table from global memory."""
+    """bmx_ctx_plan: dense test sites -> prepared pipeline, J = 16, table in LDS; every 40th SNP -> J = 4; every 200th -> one
+    test site per wave, prepared (solo); variant 2 -> the round-2 per-site kernel; variant 12 -> the round-2 grouped kernel."""
     eng, data, model, (xs, ab, As) = _synth_model()
     phys, gen, k, nn = data[0]
     N = len(gen)
@@ -36,13 +36,17 @@ def test_plan_names_the_kernel_that_runs():
     ctx.set_model(model, As)
     ctx.set_sites(gen, model.rows_of(k, nn))
     want = {1: ('clr_scan_prepared_kernel<16,true>', 4), 10: ('clr_scan_prepared_kernel<8,true>', 4),
-            40: ('clr_scan_prepared_kernel<4,true>', 4), 200: ('clr_scan_kernel<true>', -1)}
+            40: ('clr_scan_prepared_kernel<4,true>', 4), 200: ('clr_scan_solo_kernel<true>', 5)}
     for step, (name, mode) in want.items():
         idx = np.arange(0, N, step)
         ctx.set_tests(gen[idx], np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64))
         pl = ctx.plan()
         assert pl['kernel'] == name and pl['mode'] == mode, (step, pl)
-        assert (pl['stream_bytes'] > 0) == (mode == 4)
+        assert pl['stream_bytes'] > 0
+    ctx.set_variant(2)
+    ctx.set_tests(gen[idx], np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64))
+    pl = ctx.plan()
+    assert pl['kernel'] == 'clr_scan_kernel<true>' and pl['mode'] == -1 and pl['stream_bytes'] == 0
     ctx.set_variant(12)
     idx = np.arange(0, N)
     ctx.set_tests(gen[idx], np.zeros(N, np.int64), np.full(N, N - 1, np.int64))
@@ -189,16 +193,18 @@ def test_per_site_kernel_with_more_than_8191_A_values():
     ctx.set_sites(gen, rows)
     idx = np.arange(0, N, 7)
     lo, hi = np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64)
-    ctx.set_tests(gen[idx], lo, hi)
-    assert ctx.plan()['kernel'].startswith('clr_scan_kernel')
-    ctx.scan()
-    got = ctx.fetch()
     _, R = ctx.fetch_lut()
     ref = c_scan(c_oracle(), np.where(np.isfinite(R), R, 0.0), As, gen, rows, gen[idx], lo, hi)
-    for q in (1, 2, 3, 4):
-        assert np.array_equal(got[q], ref[q])
-    assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-12)
-    assert np.sum(got[3] >= 0) > 20 and np.min(got[3][got[3] >= 0]) > 8191
+    for variant, kernel in ((0, 'clr_scan_solo_kernel'), (2, 'clr_scan_kernel')):      # both one-test-site-per-wave kernels
+        ctx.set_variant(variant)
+        ctx.set_tests(gen[idx], lo, hi)
+        assert ctx.plan()['kernel'].startswith(kernel + '<')
+        ctx.scan()
+        got = ctx.fetch()
+        for q in (1, 2, 3, 4):
+            assert np.array_equal(got[q], ref[q]), (variant, q)
+        assert np.allclose(got[0], ref[0], rtol=1e-9, atol=1e-12)
+        assert np.sum(got[3] >= 0) > 20 and np.min(got[3][got[3] >= 0]) > 8191
     ctx.close()
 
 
@@ -285,3 +291,38 @@ def test_library_level_multi_gpu_one_shot():
     d = _lib.i32([0, 99])
     rc, _ = call(L.bmx_scan_multi, 2, _lib.as_ip(d))
     assert rc == -2 and b'worker 1' in L.bmx_last_error()
+
+
+@pytest.mark.parametrize('step', [60, 64, 200, 1000])
+def test_solo_pipeline_on_sparse_test_sets(step):
+    """Sparse test sets (-s 60 ... 1000) go through the one-test-site-per-wave prepared pipeline (prep_solo_kernel +
+    clr_scan_solo_kernel): identical argmax and nSites, CLR to 1e-10, against the round-2 per-site kernel (variant 2) on every
+    test site and against the C oracle on a sample; windows limited by index bounds too."""
+    eng, data, model, (xs, ab, As) = _synth_model(chroms=((2, 600000),))
+    phys, gen, k, nn = data[0]
+    N = len(gen)
+    rows = model.rows_of(k, nn)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, rows)
+    idx = np.arange(1000, N - 1000, step)[:6000]
+    M = len(idx)
+    for lo, hi in ((np.zeros(M, np.int64), np.full(M, N - 1, np.int64)),
+                   (np.maximum(idx - 300, 0).astype(np.int64), np.minimum(idx + 1500, N - 1).astype(np.int64))):
+        out = {}
+        for v in (0, 2):
+            ctx.set_variant(v)
+            ctx.set_tests(gen[idx], lo, hi)
+            assert ctx.plan()['mode'] == (5 if v == 0 else -1)
+            ctx.scan()
+            out[v] = ctx.fetch()
+        for a, b in zip(out[0][1:], out[2][1:]):
+            assert np.array_equal(a, b)
+        assert np.max(np.abs(out[0][0] - out[2][0]) / np.maximum(np.abs(out[2][0]), 1e-9)) < 1e-10
+        _, R = ctx.fetch_lut()
+        samp = np.arange(0, M, max(1, M // 32))
+        ref = c_scan(c_oracle(), np.where(np.isfinite(R), R, 0.0), As, gen, rows, gen[idx[samp]], lo[samp], hi[samp])
+        for q in (1, 2, 3, 4):
+            assert np.array_equal(out[0][q][samp], ref[q])
+        assert np.allclose(out[0][0][samp], ref[0], rtol=1e-9, atol=1e-12)
+    ctx.close()
