@@ -191,6 +191,66 @@ int bmx_input_parse(const char *path, int64_t N, int pos_col, int64_t *phys, dou
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
+// Host-side validation passes of bmx_ctx_set_sites / bmx_ctx_set_tests, on several host threads (here, not next to the
+// kernels, so that a ThreadSanitizer build of this file can run them without a GPU: tests/test_host_tsan.py).
+#include <atomic>
+#include <thread>
+#include <vector>
+
+namespace {
+// fn(t, begin, end) on T host threads over [0, n)
+template <class F>
+void io_parallel_ranges(int64_t n, int64_t grain, int max_threads, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, (unsigned)max_threads), n / std::max<int64_t>(grain, 1) + 1);
+    if (T <= 1) { fn(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(fn, t, n * t / T, n * (t + 1) / T);
+    for (auto &x : th) x.join();
+}
+}  // namespace
+
+// One pass over the site arrays: every row index inside the table and on a (k, n) with a positive neutral probability (the
+// kernels index the LDS/L2 table with it unchecked), positions sorted and not NaN; the 16- or 32-bit row indices the device
+// uses and the per-row site counts come out of the same pass.  Returns 0, or 1 row outside the table, 2 neutral probability
+// missing / not positive, 3 positions not sorted, 4 NaN position.  r16 / r32: exactly one is non-NULL; cnt[rows] is zeroed here.
+extern "C" int bmx_validate_sites_(int64_t N, const double *genpos, const int32_t *row, int32_t rows, const double *g,
+                                   uint16_t *r16, uint32_t *r32, int64_t *cnt) {
+    constexpr int MAXT = 32;
+    std::atomic<int> bad{0};             // the kind of fault seen by any thread (which one wins does not matter)
+    std::vector<int64_t> cnt_t[MAXT];
+    io_parallel_ranges(N, 1 << 18, MAXT, [&](int t, int64_t b, int64_t e) {
+        std::vector<int64_t> &c = cnt_t[t];
+        c.assign((size_t)rows, 0);
+        for (int64_t i = b; i < e; i++) {
+            const int32_t r = row[i];
+            int f = 0;
+            if (r < 0 || r >= rows) f = 1;
+            else if (!(g[(size_t)r] > 0.0)) f = 2;
+            else if (i && genpos[i] < genpos[i - 1]) f = 3;
+            else if (!(genpos[i] == genpos[i])) f = 4;
+            if (f) { bad.store(f, std::memory_order_relaxed); return; }
+            if (r32) r32[(size_t)i] = (uint32_t)r; else r16[(size_t)i] = (uint16_t)r;
+            c[(size_t)r]++;
+        }
+    });
+    for (int32_t r = 0; r < rows; r++) cnt[r] = 0;
+    for (int t = 0; t < MAXT; t++)
+        for (size_t r = 0; r < cnt_t[t].size(); r++) cnt[r] += cnt_t[t][r];
+    return bad.load();
+}
+
+// 1 if test_gen[0..M) is non-decreasing (NaN counts as unsorted), else 0
+extern "C" int bmx_tests_sorted_(int64_t M, const double *test_gen) {
+    std::atomic<int> unsorted{0};
+    io_parallel_ranges(M, 1 << 18, 32, [&](int, int64_t b, int64_t e) {
+        for (int64_t t = std::max<int64_t>(b, 1); t < e; t++)
+            if (!(test_gen[t] >= test_gen[t - 1])) { unsorted.store(1, std::memory_order_relaxed); return; }
+    });
+    return unsorted.load() ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Output writer: the 7-column rows of `scores.write(f'{phys}\t{gen}\t{T}\t{x}\t{a}\t{A}\t{n}\n')`
 // (reference BalLeRMix+_v1.py:607) for integer physPos.  Floats are printed exactly as Python's
 // repr() does: shortest digits that round-trip (std::to_chars), fixed notation when the decimal

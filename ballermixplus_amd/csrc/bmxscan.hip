@@ -2679,6 +2679,10 @@ extern "C" bmx_row_tables_ *bmx_row_tables_new_(const char *xs, int nx, const ch
 extern "C" void bmx_row_tables_free_(bmx_row_tables_ *t);
 extern "C" int bmx_write_chunk_(FILE *f, const bmx_row_tables_ *t, int64_t n, const int64_t *phys, const double *gen, const double *clr,
                                 const int32_t *ix, const int32_t *ia, const int32_t *iA, const int32_t *lin, const int32_t *nsites);
+// bmx_io.cpp: the threaded host passes of set_sites / set_tests
+extern "C" int bmx_validate_sites_(int64_t N, const double *genpos, const int32_t *row, int32_t rows, const double *g,
+                                   uint16_t *r16, uint32_t *r32, int64_t *cnt);
+extern "C" int bmx_tests_sorted_(int64_t M, const double *test_gen);
 
 // =================================================================================== ctx
 namespace {
@@ -3130,34 +3134,14 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
     const bool wide = c->rows > 65535;
     std::vector<uint16_t> r16(wide ? 0 : (size_t)N);
     std::vector<uint32_t> r32(wide ? (size_t)N : 0);
-    constexpr int MAXT = 32;
-    std::atomic<int> bad{0};             // first kind of fault seen by any thread (which one wins does not matter)
-    std::vector<int64_t> cnt_t[MAXT];
-    parallel_ranges(N, 1 << 18, [&](int t, int64_t b, int64_t e) {
-        std::vector<int64_t> &cnt = cnt_t[t];
-        cnt.assign((size_t)c->rows, 0);
-        for (int64_t i = b; i < e; i++) {
-            const int32_t r = row[i];
-            int f = 0;
-            if (r < 0 || r >= c->rows) f = 1;
-            else if (!(c->h_g[(size_t)r] > 0.0)) f = 2;
-            else if (i && genpos[i] < genpos[i - 1]) f = 3;
-            else if (!(genpos[i] == genpos[i])) f = 4;
-            if (f) { bad.store(f, std::memory_order_relaxed); return; }
-            if (wide) r32[(size_t)i] = (uint32_t)r; else r16[(size_t)i] = (uint16_t)r;
-            cnt[(size_t)r]++;
-        }
-    });
-    switch (bad.load()) {
+    std::vector<int64_t> cnt((size_t)c->rows, 0);
+    switch (bmx_validate_sites_(N, genpos, row, c->rows, c->h_g.data(), wide ? nullptr : r16.data(), wide ? r32.data() : nullptr, cnt.data())) {
         case 1: return fail(BMX_E_INVALID, "site row index outside the LUT");
         case 2: return fail(BMX_E_INVALID, "a site has a (count, sample size) whose neutral probability is missing or not positive");
         case 3: return fail(BMX_E_INVALID, "genetic positions must be non-decreasing");
         case 4: return fail(BMX_E_INVALID, "NaN genetic position");
         default: break;
     }
-    std::vector<int64_t> cnt((size_t)c->rows, 0);
-    for (int t = 0; t < MAXT; t++)
-        for (size_t r = 0; r < cnt_t[t].size(); r++) cnt[r] += cnt_t[t][r];
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     drop_sites(s);
@@ -3285,12 +3269,7 @@ int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64
         HIP_TRY(hipGetLastError());
     }
     // while the device locates the test sites: the grouped kernels need ascending test positions
-    std::atomic<int> unsorted{0};
-    parallel_ranges(M, 1 << 18, [&](int, int64_t b, int64_t e) {
-        for (int64_t t = std::max<int64_t>(b, 1); t < e; t++)
-            if (!(test_gen[t] >= test_gen[t - 1])) { unsorted.store(1, std::memory_order_relaxed); return; }
-    });
-    s->tests_sorted = !unsorted.load();
+    s->tests_sorted = bmx_tests_sorted_(M, test_gen) != 0;
     s->test_gap = 1 << 30;
     if (ns > 0) {
         std::vector<int64_t> gaps((size_t)ns);

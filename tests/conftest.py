@@ -13,18 +13,16 @@ def pytest_configure(config):
     # The in-tree library is git-ignored and travels to the GPU box as a binary: (re)build it whenever it is missing
     # or was built from other sources than the ones in the tree (bmx_build_id vs the sources' hash), so that a stale
     # binary is never what gets tested.  `make` is incremental; _lib.lib() raises if the ids still differ.
-    import ctypes
     import subprocess
     from ballermixplus_amd import _lib
     so = _lib.LIB_PATH
     stale = True
     if os.path.exists(so):
-        try:
-            L = ctypes.CDLL(so)
-            L.bmx_build_id.restype = ctypes.c_char_p
-            stale = L.bmx_build_id().decode() != _lib.source_id()
-        except (OSError, AttributeError):
-            stale = True
+        # asked in a CHILD process: a library opened here stays mapped, and the rebuilt file would never be seen by this
+        # process (dlopen returns the handle it already has) -- which once turned a stale binary into "no GPU, all skipped"
+        r = subprocess.run([sys.executable, '-c', 'import ctypes,sys; L=ctypes.CDLL(sys.argv[1]); L.bmx_build_id.restype=ctypes.c_char_p; '
+                            'print(L.bmx_build_id().decode())', so], capture_output=True, text=True)
+        stale = r.returncode != 0 or r.stdout.strip() != _lib.source_id()
     if stale:
         subprocess.run(['make', '-B', '-C', os.path.join(REPO, 'ballermixplus_amd', 'csrc')], check=False,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
