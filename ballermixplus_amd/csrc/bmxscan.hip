@@ -1359,7 +1359,7 @@ constexpr int RING_UNITS = 256, RING_MIRROR = 16, AUX_UNITS = 32;     // per wav
 constexpr int PREP_ZONE_DONE = -0x7fffffff;
 constexpr int PREP_THREADS = 256;
 constexpr int PREP_THR_LDS_MAX = 4096;                                // rows whose far thresholds are staged in LDS
-constexpr int64_t SOLO_GAP = 56;                                      // median gap between test sites beyond which groups stop paying
+constexpr int64_t SOLO_GAP = 12;                                      // median gap between test sites beyond which groups stop paying
 
 struct PrepParams {
     const double *genpos;
@@ -3316,11 +3316,12 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
     if (const char *pad = diag_env("BMX_LDS_PAD")) lds += (size_t)std::max(atoi(pad), 0);   // occupancy experiments
     P.row0 = s->nslots > 0 ? s->row_of_slot[0] : -1;
     P.wide_tab = (size_t)c->rows * c->NP * sizeof(double) >= ((size_t)1 << 32) ? 1 : 0;
-    // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3 in round 2
-    // (windows/s x1000 for J = 16 / 8 / 4 / per-site; profiles/r02_stride_table.txt): stride 1: 3005/2108/1250/-,
-    // 2: 2585/1989/1229, 3: 2115/1880/1203, 4: 1691/1780/1177, 8: 1146/1391/1075, 16: 755/1014/910, 32: 477/706/720/590,
-    // 48: 341/548/611/575, 64: 276/464/536/569, 128: 140/282/374/523 -> J by the median gap between test sites;
-    // beyond ~56 sites the per-site kernel takes over.
+    // Grouping pays while neighbouring test sites share most of their windows.  Measured on config 3 in round 3 with the
+    // prepared kernels (windows/s x1000 for J = 16 / 8 / 4 / one test site per wave; profiles/r03_stride_table.txt): stride 1:
+    // 4175/-/-/-, 2: 3133/2860/1774/1339, 4: -/2433/1677/1343, 6: -/2058/1543/1342, 8: -/1741/1474/1337, 12: -/1354/1298/1333,
+    // 16: -/1157/1158/1322, 24: -/916/957/1314, 32: -/772/836/1301, 48: -/585/687/1282, 64+: 1268 ... 1174 at 200
+    // -> J = 16 up to a median gap of 3 sites between test sites, 8 up to 12, beyond that one test site per wave.
+    // (The round-2 kernels, variant 12, keep their own thresholds: 16 / 8 / 4 up to 3 / 28 / 56, then the per-site kernel.)
     const int64_t gap_max = diag_env("BMX_DENSE_GAP") ? atoll(diag_env("BMX_DENSE_GAP")) : 56;
     const bool can_group = s->tests_sorted && s->test_gap <= gap_max && c->span_hi <= 62 && s->N < 0x7fffffffLL && c->nA < 8191 && !P.wide_tab;
     int J = 0;
@@ -3338,7 +3339,8 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
     if (can_group && !solo) {
         J = (v == 0 || v == 12 || v == 5 || v == 8 || v == 10 || v == 13) ? 16 : (v == 3 || v == 6 || v == 9 || v == 11 || v == 14) ? 8
             : (v == 4 || v == 7 || v == 15) ? 4 : 0;
-        if (v == 0 || v == 12) J = s->test_gap <= 3 ? 16 : s->test_gap <= 28 ? 8 : 4;
+        if (v == 12) J = s->test_gap <= 3 ? 16 : s->test_gap <= 28 ? 8 : 4;
+        if (v == 0) J = s->test_gap <= 3 ? 16 : 8;                  // (gaps beyond SOLO_GAP never get here: solo)
         if ((v == 0 || v == 12) && diag_env("BMX_FORCE_J")) {                    // threshold experiments: 16, 8 or 4
             const int fj = atoi(diag_env("BMX_FORCE_J"));
             if (fj != 16 && fj != 8 && fj != 4) return fail(BMX_E_INVALID, "BMX_FORCE_J must be 16, 8 or 4");

@@ -27,7 +27,7 @@ def _synth_model(n=100, chroms=((1, 200000),), bal=False):
 
 
 def test_plan_names_the_kernel_that_runs():
-    """bmx_ctx_plan: dense test sites -> prepared pipeline, J = 16, table in LDS; every 40th SNP -> J = 4; every 200th -> one
+    """bmx_ctx_plan: dense test sites -> prepared pipeline, J = 16, table in LDS; every 10th SNP -> J = 8; every 13th or 200th -> one
     test site per wave, prepared (solo); variant 2 -> the round-2 per-site kernel; variant 12 -> the round-2 grouped kernel."""
     eng, data, model, (xs, ab, As) = _synth_model()
     phys, gen, k, nn = data[0]
@@ -35,8 +35,8 @@ def test_plan_names_the_kernel_that_runs():
     ctx = eng.Context(0)
     ctx.set_model(model, As)
     ctx.set_sites(gen, model.rows_of(k, nn))
-    want = {1: ('clr_scan_prepared_kernel<16,true>', 4), 10: ('clr_scan_prepared_kernel<8,true>', 4),
-            40: ('clr_scan_prepared_kernel<4,true>', 4), 200: ('clr_scan_solo_kernel<true>', 5)}
+    want = {1: ('clr_scan_prepared_kernel<16,true>', 4), 3: ('clr_scan_prepared_kernel<16,true>', 4), 10: ('clr_scan_prepared_kernel<8,true>', 4),
+            13: ('clr_scan_solo_kernel<true>', 5), 200: ('clr_scan_solo_kernel<true>', 5)}
     for step, (name, mode) in want.items():
         idx = np.arange(0, N, step)
         ctx.set_tests(gen[idx], np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64))
@@ -54,8 +54,8 @@ def test_plan_names_the_kernel_that_runs():
     ctx.close()
 
 
-@pytest.mark.parametrize('step,J', [(1, 16), (2, 16), (5, 8), (30, 4)])
-def test_prepared_pipeline_equals_round2_kernel_and_oracle(step, J):
+@pytest.mark.parametrize('step,J,v0,v12', [(1, 16, 0, 12), (2, 16, 0, 12), (5, 8, 0, 12), (30, 4, 15, 12)])
+def test_prepared_pipeline_equals_round2_kernel_and_oracle(step, J, v0, v12):
     """The prepared pipeline (variant 0) against the round-2 grouped kernel (variant 12: same group size) on 32k config-3
     windows at several test-site strides: identical argmax and nSites, CLR to 1e-10 (the two differ only in which sites
     count as far: one threshold per row instead of one per row and slice); and against the C oracle on a sample."""
@@ -72,12 +72,13 @@ def test_prepared_pipeline_equals_round2_kernel_and_oracle(step, J):
     M = len(idx)
     lo, hi = np.zeros(M, np.int64), np.full(M, N - 1, np.int64)
     out = {}
-    for v in (0, 12):
+    for key, v in ((0, v0), (12, v12)):      # (J = 4 is no longer what the default plan picks at any stride: variant 15 asks for it)
         ctx.set_variant(v)
         ctx.set_tests(gen[idx], lo, hi)
-        assert ctx.plan()['J'] == J
+        pl = ctx.plan()
+        assert pl['J'] == J and pl['mode'] == (4 if key == 0 else 3)
         ctx.scan()
-        out[v] = ctx.fetch()
+        out[key] = ctx.fetch()
     for a, b in zip(out[0][1:], out[12][1:]):
         assert np.array_equal(a, b)
     assert np.max(np.abs(out[0][0] - out[12][0]) / np.maximum(np.abs(out[12][0]), 1e-9)) < 1e-10
@@ -293,7 +294,7 @@ def test_library_level_multi_gpu_one_shot():
     assert rc == -2 and b'worker 1' in L.bmx_last_error()
 
 
-@pytest.mark.parametrize('step', [60, 64, 200, 1000])
+@pytest.mark.parametrize('step', [14, 64, 200, 1000])
 def test_solo_pipeline_on_sparse_test_sets(step):
     """Sparse test sets (-s 60 ... 1000) go through the one-test-site-per-wave prepared pipeline (prep_solo_kernel +
     clr_scan_solo_kernel): identical argmax and nSites, CLR to 1e-10, against the round-2 per-site kernel (variant 2) on every
