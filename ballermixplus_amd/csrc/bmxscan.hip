@@ -2421,8 +2421,17 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_solo_kernel(ScanParams 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = blockDim.x / WAVE;
-    const int slice = blockIdx.x % P.nslices;   // blocks b, b+8 share an XCD: one R slice per L2
+#if BMX_XCD_MAP
+    // the slices of one chunk of test sites on one XCD, next to each other in its dispatch order (see the prepared kernel): the
+    // blobs are 100 KB per test site here and every slice reads all of them
+    const int xcd = blockIdx.x & 7;
+    const int64_t q = blockIdx.x >> 3;
+    const int slice = (int)(q % P.nslices);
+    const int64_t chunk = (q / P.nslices) * 8 + xcd;
+#else
+    const int slice = blockIdx.x % P.nslices;
     const int64_t chunk = blockIdx.x / P.nslices;
+#endif
     const int p = slice * WAVE + lane;
     if (USE_LDS) {
         const int total = P.rows * WAVE;
@@ -2443,25 +2452,32 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_solo_kernel(ScanParams 
     const int64_t t_begin = chunk * P.sites_per_block;
     const int64_t t_end = min(t_begin + (int64_t)P.sites_per_block, P.M);
     for (int64_t t = t_begin + wave; t < t_end; t += nw) {
+        // the stream of this test site through the ring: a wave uses up a chunk of 64 entries in ~0.4 us, less than a trip to
+        // memory, so TWO chunks are in flight behind the (up to) two staged ahead of the read position
         const double2 *src = reinterpret_cast<const double2 *>(V.arena + (V.blob_prefix[V.grp_base + t] - V.prefix_base));
         int pos = 0, staged_u = 0;
-        double nx_a, nx_b;
+        double nx_a, nx_b, ny_a, ny_b;
         {
-            const double2 q = src[lane];
-            nx_a = q.x; nx_b = q.y;
+            const double2 q0 = src[lane], q1 = src[WAVE + lane];
+            nx_a = q0.x; nx_b = q0.y;
+            ny_a = q1.x; ny_b = q1.y;
         }
         auto stage = [&]() {
             const int slot = (staged_u >> 6) & 3;
             ring2[slot * WAVE + lane] = double2{nx_a, nx_b};
             if (slot == 0 && lane < RING_MIRROR) ring2[RING_UNITS + lane] = double2{nx_a, nx_b};
             staged_u += WAVE;
-            const double2 q = src[staged_u + lane];
-            nx_a = q.x; nx_b = q.y;
+            nx_a = ny_a; nx_b = ny_b;
+            const double2 q1 = src[staged_u + WAVE + lane];
+            ny_a = q1.x; ny_b = q1.y;
             __builtin_amdgcn_wave_barrier();
         };
+        // [pos, pos + 144) is in the ring (pos moves by at most 64 units between two calls; the slot a step overwrites lies
+        // more than 16 units behind pos: staged_u <= pos + 144 before the step, 4 slots of 64)
         auto need = [&]() {
-            if (pos + 80 > staged_u) stage();
+            if (pos + 144 > staged_u) stage();
         };
+        stage();
         stage();
         stage();
         bool bad = false;
@@ -3491,7 +3507,7 @@ int ensure_prep(bmx_ctx *c, ChromSlot *s) {
         need = std::max(need, units);
         g0 = g1;
     }
-    HIP_TRY(c->arena.ensure((size_t)need + 4 * WAVE));     // the consumer's read-ahead runs up to three chunks past a blob's end
+    HIP_TRY(c->arena.ensure((size_t)need + 8 * WAVE));     // the consumers' read-ahead runs up to five chunks past a blob's end
     TRACE("prepared: %lld groups, %.1f MB of blobs, %zu launch range(s), arena %.1f MB", (long long)ngroups, (double)pre[(size_t)ngroups] * 16e-6,
           s->ranges.size(), (double)c->arena.cap * 16e-6);
     s->prep_ok = true;
@@ -3521,10 +3537,10 @@ int launch_range(bmx_ctx *c, ChromSlot *s, ScanPlan &pl, int64_t off, int64_t cn
     P.center = s->center.p + off; P.center_hi = s->center_hi.p + off; P.M = cnt;
     P.part_T = c->part_T.p; P.part_lin = c->part_lin.p; P.part_ns = c->part_ns.p;
     int64_t blocks = (cnt + pl.spb - 1) / pl.spb * c->nslices;
-    if (pr && BMX_XCD_MAP && pl.mode == 4) blocks = ((cnt + pl.spb - 1) / pl.spb + 7) / 8 * 8 * c->nslices;     // chunks padded to whole XCD rounds
+    if (pr && BMX_XCD_MAP) blocks = ((cnt + pl.spb - 1) / pl.spb + 7) / 8 * 8 * c->nslices;     // chunks padded to whole XCD rounds
     if (pr) {
         // the range's blobs: filled by the per-group kernel, then consumed by one wave per (group, slice)
-        if ((size_t)pr->units + 4 * WAVE > c->arena.cap) HIP_TRY(c->arena.ensure((size_t)pr->units + 4 * WAVE));
+        if ((size_t)pr->units + 8 * WAVE > c->arena.cap) HIP_TRY(c->arena.ensure((size_t)pr->units + 8 * WAVE));
         PrepParams Q = prep_params(c, s, pl);
         Q.g_begin = pr->g0; Q.g_end = pr->g0 + pr->ng; Q.prefix_base = pr->pbase;
         const int gpw = pl.prep_threads / WAVE;
