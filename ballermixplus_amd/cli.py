@@ -229,6 +229,7 @@ def main_many(opt, files, stamp=lambda what: None):
     th.start()
     ctx = None
     tables = 0
+    kernel_ms = 0.0
     for i, (infile, outfile) in enumerate(zip(files, outs)):
         th.join()
         got = nxt.pop(i)
@@ -244,9 +245,14 @@ def main_many(opt, files, stamp=lambda what: None):
              noCenter=opt.noCenter, runner=runner, verbose=False, keep_results=False, reuse_ctx=ctx)
         ctx = sel.ctx
         tables += 0 if sel.table_reused else 1
+        try:
+            kernel_ms += ctx.last_scan_ms()
+        except Exception:           # a file without test sites
+            pass
         stamp('file %d of %d' % (i + 1, len(files)))
     world.finish()
-    say(f'\n{datetime.now()}. Pipeline finished: {len(files)} files, selection table built {tables} time(s).')
+    say(f'\n{datetime.now()}. Pipeline finished: {len(files)} files, selection table built {tables} time(s), '
+        f'scan kernels {kernel_ms / 1e3:.2f} s.')
 
 
 if __name__ == '__main__':

@@ -103,6 +103,9 @@ constexpr int MOM_SLOTS_LDS = 64;             // ... of which this many are used
 #ifndef BMX_XCD_MAP
 #define BMX_XCD_MAP 1     // prepared kernel: the slices of a chunk of test sites on one XCD (4.168 -> 4.205 M windows/s, HBM reads / 8)
 #endif
+#ifndef BMX_SOLO_XCD_MAP
+#define BMX_SOLO_XCD_MAP 0     // measured: no change for the solo kernel (1.219 vs 1.216 M windows/s)
+#endif
 #ifndef BMX_PRIV01
 #define BMX_PRIV01 1
 #endif
@@ -1353,9 +1356,41 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 // the test sites are set, then an exclusive scan; the fill pass (prep_kernel<J, true>) and the consumer run per launch range.
 // The far test is slice-independent now: alpha * max_grid |R[row]| <= far_eps, evaluated in the exponent domain
 // (A d >= log(max|R| / far_eps), rounded up), so both passes classify from A d alone.
-constexpr int PREP_HDR = 3, PREP_GUARD = 8, PREP_MOM = 5, PREP_RAG_GUARD = 1;
+// Far field of the prepared kernels: log1p(x) = sum_k (-1)^(k+1) w_k x^k to order P_ORDER on |x| <= P_EPS, coefficients economised
+// on that interval (scripts/far_series.py: Taylor polynomial of degree 40 re-expanded in Chebyshev polynomials of x / eps, cut after
+// T_K, constant term < 3e-17 dropped).  Order 12 on [-0.15, 0.15]: max error 4.5e-16 (the round-2 kernels: order 8 on [-0.05, 0.05],
+// 8.9e-16) -- the far field starts 1.1 units of A d nearer to the test sites, and the near lists, half of the scan kernel's
+// instructions, lose a third of their entries.
+#ifndef BMX_P_ORDER
+#define BMX_P_ORDER 12
+#endif
+constexpr int P_ORDER = BMX_P_ORDER;
+constexpr int P_COPIES = 4;                   // copies of the most frequent row's moments (lane % 4); P_COPIES * P_ORDER <= 64
+static_assert(P_ORDER == 8 || P_ORDER == 12 || P_ORDER == 16, "far-field order of the prepared kernels: 8, 12 or 16");
+static_assert(P_COPIES * P_ORDER <= WAVE, "slot-0 copies must fit one wave-wide read");
+constexpr double P_EPS = P_ORDER == 16 ? 0.25 : P_ORDER == 12 ? 0.15 : 0.05;
+constexpr int P_FAR_CAP = P_ORDER == 16 ? 2048 : P_ORDER == 12 ? 3584 : 8192;     // far sites per zone: P_FAR_CAP * P_EPS * 1.6 bits < 1000
+#if BMX_P_ORDER == 16
+__device__ constexpr double P_W[16] = {0.9999999999999954, 0.4999999999999791, 0.3333333333368442, 0.250000000008901, 0.19999999921757028,
+                                       0.1666666652123534, 0.14285722101681053, 0.1250001188192722, 0.11110698172974029, 0.09999456222768308,
+                                       0.09103227543438049, 0.08347880124963403, 0.07484961178075682, 0.06918273076087589, 0.08475562956871537,
+                                       0.08074032343426385};
+// a lane adds E^k (k >= 3) only while its term can exceed 2e-15: d = A d - threshold < P_D[k - 3]  (x = P_EPS exp(-d))
+__device__ constexpr double P_D[14] = {9.539, 6.739, 5.071, 3.966, 3.181, 2.594, 2.14, 1.778, 1.483, 1.237, 1.03, 0.853, 0.7, 0.566};
+#elif BMX_P_ORDER == 12
+__device__ constexpr double P_W[12] = {0.9999999999999661, 0.49999999999988076, 0.3333333333754503, 0.25000000008463336, 0.19999998506452038,
+                                       0.1666666441614055, 0.14285940976674, 0.1250028457483109, 0.11094429253027539, 0.09981580095968261,
+                                       0.09676290425438011, 0.08920395582674094};
+__device__ constexpr double P_D[10] = {9.029, 6.228, 4.56, 3.455, 2.67, 2.084, 1.629, 1.267, 0.972, 0.726};
+#else
+__device__ constexpr double P_W[8] = {0.9999999999998467, 0.4999999999996164, 0.3333333341509627, 0.25000000122701976,
+                                      0.19999882322703955, 0.16666529319200146, 0.1434841013671569, 0.12562715480255862};
+__device__ constexpr double P_D[6] = {7.94, 5.13, 3.462, 2.357, 1.571, 0.985};
+#endif
+constexpr double P_RAG_D = P_ORDER == 16 ? 6.74 : P_ORDER == 12 ? 6.23 : 5.13;     // log(P_EPS / 3e-4): the ragged end's third-order test
+constexpr int PREP_HDR = 3, PREP_GUARD = 8, PREP_MOM = 1 + P_ORDER / 2, PREP_RAG_GUARD = 1;     // a moment entry: (M_1, row) + M_2 .. M_K in pairs
 constexpr int PREP_MAGIC = 0x5a0e0000;
-constexpr int RING_UNITS = 256, RING_MIRROR = 16, AUX_UNITS = 32;     // per wave: ring of 4 x 64 units + 16 mirrored + scratch
+constexpr int RING_UNITS = 256, RING_MIRROR = 32, AUX_UNITS = 32;     // per wave: ring of 4 x 64 units + 32 mirrored + scratch
 constexpr int PREP_ZONE_DONE = -0x7fffffff;
 constexpr int PREP_THREADS = 256;
 constexpr int PREP_THR_LDS_MAX = 4096;                                // rows whose far thresholds are staged in LDS
@@ -1399,7 +1434,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
     }
     // per wave: the moments of the right and of the left zone of one A (the stream holds both zones' near lists before either
     // zone's moments, so the right zone's sums wait while the left zone is walked), then 64 doubles of scratch
-    const int mom_len = (P.mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER;
+    const int mom_len = (P.mom_slots + P_COPIES - 1 + 3) * P_ORDER;
     double *mom_r = lds_p + thr_len + wave * (2 * mom_len + WAVE);
     double *mom_l = mom_r + mom_len;
     double *ragscr = mom_l + mom_len;
@@ -1473,7 +1508,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                     const double zn = A * fabs(g - tnear);
                     const double th = thr_of(rraw);
                     const int slot = __double2loint(th) & 0xff;
-                    const bool moml = bulk && slot < kmom && zn >= th && nfar_tot < FAR_CAP;
+                    const bool moml = bulk && slot < kmom && zn >= th && nfar_tot < P_FAR_CAP;
                     const bool nearl = bulk && !moml;
                     const bool pairl = nearl && zn < LN2;
                     const unsigned long long mm = __ballot(moml), mp = __ballot(pairl), mq = __ballot(nearl && !pairl);
@@ -1483,33 +1518,22 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                     if (FILL) Ev = bulk ? exp_neg(zn) : 0.0;
                     if (nfar) {
                         if (moml) {
-                            double *mr = mom + (slot ? slot + MOM_COPIES - 1 : (lane & (MOM_COPIES - 1))) * FAR_ORDER;
+                            double *mr = mom + (slot ? slot + P_COPIES - 1 : (lane & (P_COPIES - 1))) * P_ORDER;
                             if (FILL) {
                                 // a lane adds only the powers whose term can exceed 2e-15: x = alpha max|R| = far_eps exp(-(z - th))
                                 const double d = zn - th;
                                 const double E2 = Ev * Ev;
                                 if (slot == 0) { m1p += Ev; m2p += E2; }
                                 else { atomicAdd(mr, Ev); atomicAdd(mr + 1, E2); }
-                                if (d < 7.94) {
-                                    const double E3 = E2 * Ev;
-                                    atomicAdd(mr + 2, E3);
-                                    if (d < 5.13) {
-                                        const double E4 = E2 * E2;
-                                        atomicAdd(mr + 3, E4);
-                                        if (d < 3.46) {
-                                            atomicAdd(mr + 4, E4 * Ev);
-                                            if (d < 2.36) {
-                                                atomicAdd(mr + 5, E4 * E2);
-                                                if (d < 1.58) {
-                                                    atomicAdd(mr + 6, E4 * E3);
-                                                    if (d < 0.99) atomicAdd(mr + 7, E4 * E4);
-                                                }
-                                            }
-                                        }
-                                    }
+                                double Ek = E2;
+#pragma unroll
+                                for (int k = 3; k <= P_ORDER; ++k) {
+                                    if (!(d < P_D[k - 3])) break;
+                                    Ek *= Ev;
+                                    atomicAdd(mr + (k - 1), Ek);
                                 }
                             } else {
-                                mom[(slot ? slot + MOM_COPIES - 1 : 0) * FAR_ORDER] = 1.0;      // occupancy only
+                                mom[(slot ? slot + P_COPIES - 1 : 0) * P_ORDER] = 1.0;      // occupancy only
                             }
                         }
                         nfar_tot += nfar;
@@ -1571,7 +1595,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                 }
                 if (okr && nrmax > 0 && nrmax < WAVE) {
                     zr = A * fabs(g - tnear);
-                    const bool far3 = lane >= nrmax || zr >= thr_of(rr) + 5.13;      // alpha max|R| <= 3e-4; NaN (absent row): false
+                    const bool far3 = lane >= nrmax || zr >= thr_of(rr) + P_RAG_D;      // alpha max|R| <= 3e-4; NaN (absent row): false
                     rag = __ballot(far3) == ~0ull;
                 }
             }
@@ -1584,38 +1608,35 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
             int n_occ = 0;
             if (nfar_tot) {
                 __builtin_amdgcn_wave_barrier();
-                {   // slot 0: MOM_COPIES copies read lane-parallel (copy = lane / order, moment = lane % order) + the private sums
+                {   // slot 0: P_COPIES copies read lane-parallel (copy = lane / order, moment = lane % order) + the private sums
                     double x = 0.0;
-                    if (lane < MOM_COPIES * FAR_ORDER) {
+                    if (lane < P_COPIES * P_ORDER) {
                         x = mom[lane];
                         mom[lane] = 0.0;
                     }
                     if (FILL) {
                         double y1 = m1p, y2 = m2p;
 #pragma unroll
-                        for (int off = 1; off < FAR_ORDER; off <<= 1) {
+                        for (int off = 1; off < WAVE; off <<= 1) {
                             y1 += __shfl_xor(y1, off);
                             y2 += __shfl_xor(y2, off);
                         }
-                        const int k8 = lane & (FAR_ORDER - 1);
-                        x += k8 == 0 ? y1 : k8 == 1 ? y2 : 0.0;
+                        x += lane == 0 ? y1 : lane == 1 ? y2 : 0.0;       // copy 0, orders 1 and 2
                     }
 #pragma unroll
-                    for (int c = MOM_COPIES / 2; c >= 1; c >>= 1) x += __shfl_down(x, c * FAR_ORDER);
+                    for (int c = P_COPIES / 2; c >= 1; c >>= 1) x += __shfl_down(x, c * P_ORDER);
                     const double m0 = readlane_f64(x, 0);
                     if (m0 != 0.0) {
                         if (FILL) {
-                            double m[FAR_ORDER];
+                            double m[P_ORDER];
 #pragma unroll
-                            for (int k = 0; k < FAR_ORDER; ++k) m[k] = readlane_f64(x, k);
+                            for (int k = 0; k < P_ORDER; ++k) m[k] = readlane_f64(x, k);
                             if (lane == 0) {
                                 ScratchEnt *o = out + wpos;
                                 o[0] = ScratchEnt{m[0], P.row_of_slot[0] * P.rowmul, 0};
                                 double2 *o2 = reinterpret_cast<double2 *>(o + 1);
-                                o2[0] = double2{m[1], m[2]};
-                                o2[1] = double2{m[3], m[4]};
-                                o2[2] = double2{m[5], m[6]};
-                                o2[3] = double2{m[7], 0.0};
+                                #pragma unroll
+                                for (int q = 0; q < P_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < P_ORDER ? m[2 * q + 2] : 0.0};
                             }
                         }
                         n_occ = 1;
@@ -1623,13 +1644,13 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                 }
                 for (int s0 = 1; s0 < kmom; s0 += WAVE) {
                     const int s = s0 + lane;
-                    double m[FAR_ORDER];
+                    double m[P_ORDER];
 #pragma unroll
-                    for (int k = 0; k < FAR_ORDER; ++k) m[k] = 0.0;
+                    for (int k = 0; k < P_ORDER; ++k) m[k] = 0.0;
                     if (s < kmom) {
-                        double *ms = mom + (s + MOM_COPIES - 1) * FAR_ORDER;
+                        double *ms = mom + (s + P_COPIES - 1) * P_ORDER;
 #pragma unroll
-                        for (int k = 0; k < FAR_ORDER; ++k) { m[k] = ms[k]; ms[k] = 0.0; }
+                        for (int k = 0; k < P_ORDER; ++k) { m[k] = ms[k]; ms[k] = 0.0; }
                     }
                     const bool occ = m[0] != 0.0;
                     const unsigned long long mo = __ballot(occ);
@@ -1637,10 +1658,8 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                         ScratchEnt *o = out + wpos + PREP_MOM * (n_occ + rank(mo));
                         o[0] = ScratchEnt{m[0], P.row_of_slot[s] * P.rowmul, 0};
                         double2 *o2 = reinterpret_cast<double2 *>(o + 1);
-                        o2[0] = double2{m[1], m[2]};
-                        o2[1] = double2{m[3], m[4]};
-                        o2[2] = double2{m[5], m[6]};
-                        o2[3] = double2{m[7], 0.0};
+                        #pragma unroll
+                        for (int q = 0; q < P_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < P_ORDER ? m[2 * q + 2] : 0.0};
                     }
                     n_occ += __popcll(mo);
                 }
@@ -2043,19 +2062,21 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 double F[J];
 #pragma unroll
                 for (int j = 0; j < J; ++j) F[j] = readlane_f64(fv, j);
-                double pk[FAR_ORDER];
+                double pk[P_ORDER];
 #pragma unroll
-                for (int k = 0; k < FAR_ORDER; ++k) pk[k] = 0.0;
-                auto fold = [&](const double m1, const double2 ma, const double2 mb, const double2 mc, const double2 md, const double R) {
-                    const double R2 = R * R, R3 = R2 * R, R4 = R2 * R2;
+                for (int k = 0; k < P_ORDER; ++k) pk[k] = 0.0;
+                // p_k += M_k R^k for one moment entry (q: its units 1.. as (M_2, M_3), (M_4, M_5), ...); powers by halving: depth log2 k
+                auto fold = [&](const double m1, const double2 *q, const double R) {
+                    double pw[P_ORDER + 1];
+                    pw[1] = R;
+#pragma unroll
+                    for (int k = 2; k <= P_ORDER; ++k) pw[k] = pw[k >> 1] * pw[k - (k >> 1)];
                     pk[0] = fma(m1, R, pk[0]);
-                    pk[1] = fma(ma.x, R2, pk[1]);
-                    pk[2] = fma(ma.y, R3, pk[2]);
-                    pk[3] = fma(mb.x, R4, pk[3]);
-                    pk[4] = fma(mb.y, R4 * R, pk[4]);
-                    pk[5] = fma(mc.x, R4 * R2, pk[5]);
-                    pk[6] = fma(mc.y, R4 * R3, pk[6]);
-                    pk[7] = fma(md.x, R4 * R4, pk[7]);
+#pragma unroll
+                    for (int k = 2; k <= P_ORDER; ++k) {
+                        const double2 v = q[(k - 2) >> 1];
+                        pk[k - 1] = fma((k & 1) ? v.y : v.x, pw[k], pk[k - 1]);
+                    }
                 };
                 for (int s = 0; s < n_occ; s += 2) {
                     need();
@@ -2063,20 +2084,13 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     const bool two = s + 1 < n_occ;
                     const ScratchEnt ua = rp[0], ub = rp[two ? PREP_MOM : 0];
                     const double Ra = loadR(ua.ro), Rb2 = loadR(ub.ro);
-                    const double2 *qa = reinterpret_cast<const double2 *>(rp + 1);
-                    const double2 a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
-                    fold(ua.e, a0, a1, a2, a3, Ra);
-                    if (two) {
-                        const double2 *qb = reinterpret_cast<const double2 *>(rp + PREP_MOM + 1);
-                        const double2 b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3];
-                        fold(ub.e, b0, b1, b2, b3, Rb2);
-                    }
+                    fold(ua.e, reinterpret_cast<const double2 *>(rp + 1), Ra);
+                    if (two) fold(ub.e, reinterpret_cast<const double2 *>(rp + PREP_MOM + 1), Rb2);
                     pos += two ? 2 * PREP_MOM : PREP_MOM;
                 }
                 need();
-                spend(2 + (int)((float)(nfar_tot + nrmax) * P.far_bits));
 #pragma unroll
-                for (int k = 0; k < FAR_ORDER; ++k) pk[k] *= FAR_W[k];
+                for (int k = 0; k < P_ORDER; ++k) pk[k] *= P_W[k];
                 int l = 0;
                 double rag_e = 0.0, rag_R = 0.0;
                 if (rag) {
@@ -2100,9 +2114,9 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         }
                     }
                     const double f = F[j];
-                    double t = pk[FAR_ORDER - 1];
+                    double t = pk[P_ORDER - 1];
 #pragma unroll
-                    for (int k = FAR_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
+                    for (int k = P_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
                     farg[j] = fma(-f, t, farg[j]);              // exp_neg's argument: the factor is exp(f t)
                 }
                 if (rag) pos += nrmax + PREP_RAG_GUARD;
@@ -2167,16 +2181,32 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 double farg[J];
 #pragma unroll
                 for (int j = 0; j < J; ++j) farg[j] = 0.0;
-                zone_far(std::integral_constant<int, +1>{}, fvR, noccR, nfarR, nrmR, ragR, nrvR, farg);
-                zone_far(std::integral_constant<int, -1>{}, fvL, noccL, nfarL, nrmL, ragL, nrvL, farg);
+                auto apply_far = [&]() {
 #pragma unroll
-                for (int w = 0; w < J; w += 2) {
-                    double e0, e1;
-                    exp_neg2(farg[w], farg[w + 1], e0, e1);
-                    acc[w] *= e0;
-                    acc[w + 1] *= e1;
-                    asm volatile("" : "+v"(acc[w]), "+v"(acc[w + 1]));
+                    for (int w = 0; w < J; w += 2) {
+                        double e0, e1;
+                        exp_neg2(farg[w], farg[w + 1], e0, e1);
+                        acc[w] *= e0;
+                        acc[w + 1] *= e1;
+                        asm volatile("" : "+v"(acc[w]), "+v"(acc[w + 1]));
+                        farg[w] = 0.0;
+                        farg[w + 1] = 0.0;
+                    }
+                };
+                // exponent budget: a zone's far field moves a product by at most (sites) * far_bits bits (< 860 by P_FAR_CAP); both
+                // zones in one exp only while their sum fits, else one after the other with the exponents pulled out in between
+                const int bitsR = 2 + (int)((float)(nfarR + nrmR) * P.far_bits), bitsL = 2 + (int)((float)(nfarL + nrmL) * P.far_bits);
+                zone_far(std::integral_constant<int, +1>{}, fvR, noccR, nfarR, nrmR, ragR, nrvR, farg);
+                if (bitsR + bitsL > 900) {
+                    spend(bitsR);
+                    apply_far();
+                    zone_far(std::integral_constant<int, -1>{}, fvL, noccL, nfarL, nrmL, ragL, nrvL, farg);
+                    spend(bitsL);
+                } else {
+                    zone_far(std::integral_constant<int, -1>{}, fvL, noccL, nfarL, nrmL, ragL, nrvL, farg);
+                    spend(bitsR + bitsL);
                 }
+                apply_far();
             }
 
             renorm_all();
@@ -2226,6 +2256,16 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
 //                     4 guard entries; n_occ moment entries of 5 units
 constexpr int SOLO_MAGIC = 0x50100000;
 constexpr int SOLO_GUARD = 4;
+// Far field of the solo kernels: order 8 on |x| <= 0.05 (the round-2 series).  With one test site per wave the fold of the moments
+// (order x occupied rows per A, nothing to share it among) weighs as much as the near list, and order 12 measured slower here
+// (1.27 -> 1.14 M windows/s at stride 64) while it is faster for groups of 16.  The per-row thresholds on the device are
+// those of the grouped kernels (P_EPS): a site is far here S_SHIFT = log(P_EPS / S_EPS) later.
+constexpr int S_ORDER = 8, S_COPIES = 8, S_MOM = 1 + S_ORDER / 2, S_FAR_CAP = 8192;
+constexpr double S_EPS = 0.05;
+constexpr double S_SHIFT = P_ORDER == 16 ? 1.6095 : P_ORDER == 12 ? 1.0987 : 0.0;
+__device__ constexpr double S_W[8] = {0.9999999999998467, 0.4999999999996164, 0.3333333341509627, 0.25000000122701976,
+                                      0.19999882322703955, 0.16666529319200146, 0.1434841013671569, 0.12562715480255862};
+__device__ constexpr double S_D[6] = {7.94, 5.13, 3.462, 2.357, 1.571, 0.985};
 
 template <bool FILL>
 __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
@@ -2239,7 +2279,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
         for (int idx = threadIdx.x; idx < P.rows; idx += blockDim.x) lds_p[idx] = P.rowthr[idx];
         __syncthreads();
     }
-    const int mom_len = (P.mom_slots + MOM_COPIES - 1 + 3) * FAR_ORDER;
+    const int mom_len = (P.mom_slots + S_COPIES - 1 + 3) * S_ORDER;
     double *mom = lds_p + thr_len + wave * mom_len;
     for (int idx = lane; idx < mom_len; idx += WAVE) mom[idx] = 0.0;
     __builtin_amdgcn_wave_barrier();
@@ -2285,9 +2325,10 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
                 const bool in = valid && (zn <= P.zcut) && (g != tg);
                 const unsigned long long m_in = __ballot(in);
                 if (m_in != 0ull) {
-                    const double th = thr_of(rraw);
-                    const int slot = __double2loint(th) & 0xff;
-                    const bool moml = in && slot < kmom && zn >= th && nfar_tot < FAR_CAP;
+                    const double th0 = thr_of(rraw);
+                    const int slot = __double2loint(th0) & 0xff;
+                    const double th = th0 + S_SHIFT;                    // (NaN stays NaN: rows absent from the helper file are never far)
+                    const bool moml = in && slot < kmom && zn >= th && nfar_tot < S_FAR_CAP;
                     const bool nearl = in && !moml;
                     const unsigned long long mm = __ballot(moml), mn = __ballot(nearl);
                     const int nfar = __popcll(mm);
@@ -2296,32 +2337,21 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
                     if (FILL) Ev = in ? exp_neg(zn) : 0.0;
                     if (nfar) {
                         if (moml) {
-                            double *mr = mom + (slot ? slot + MOM_COPIES - 1 : (lane & (MOM_COPIES - 1))) * FAR_ORDER;
+                            double *mr = mom + (slot ? slot + S_COPIES - 1 : (lane & (S_COPIES - 1))) * S_ORDER;
                             if (FILL) {
                                 const double d = zn - th;
                                 const double E2 = Ev * Ev;
                                 if (slot == 0) { m1p += Ev; m2p += E2; }
                                 else { atomicAdd(mr, Ev); atomicAdd(mr + 1, E2); }
-                                if (d < 7.94) {
-                                    const double E3 = E2 * Ev;
-                                    atomicAdd(mr + 2, E3);
-                                    if (d < 5.13) {
-                                        const double E4 = E2 * E2;
-                                        atomicAdd(mr + 3, E4);
-                                        if (d < 3.46) {
-                                            atomicAdd(mr + 4, E4 * Ev);
-                                            if (d < 2.36) {
-                                                atomicAdd(mr + 5, E4 * E2);
-                                                if (d < 1.58) {
-                                                    atomicAdd(mr + 6, E4 * E3);
-                                                    if (d < 0.99) atomicAdd(mr + 7, E4 * E4);
-                                                }
-                                            }
-                                        }
-                                    }
+                                double Ek = E2;
+#pragma unroll
+                                for (int k = 3; k <= S_ORDER; ++k) {
+                                    if (!(d < S_D[k - 3])) break;
+                                    Ek *= Ev;
+                                    atomicAdd(mr + (k - 1), Ek);
                                 }
                             } else {
-                                mom[(slot ? slot + MOM_COPIES - 1 : 0) * FAR_ORDER] = 1.0;
+                                mom[(slot ? slot + S_COPIES - 1 : 0) * S_ORDER] = 1.0;
                             }
                         }
                         nfar_tot += nfar;
@@ -2344,36 +2374,33 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
             __builtin_amdgcn_wave_barrier();
             {
                 double x = 0.0;
-                if (lane < MOM_COPIES * FAR_ORDER) {
+                if (lane < S_COPIES * S_ORDER) {
                     x = mom[lane];
                     mom[lane] = 0.0;
                 }
                 if (FILL) {
                     double y1 = m1p, y2 = m2p;
 #pragma unroll
-                    for (int off = 1; off < FAR_ORDER; off <<= 1) {
+                    for (int off = 1; off < WAVE; off <<= 1) {
                         y1 += __shfl_xor(y1, off);
                         y2 += __shfl_xor(y2, off);
                     }
-                    const int k8 = lane & (FAR_ORDER - 1);
-                    x += k8 == 0 ? y1 : k8 == 1 ? y2 : 0.0;
+                    x += lane == 0 ? y1 : lane == 1 ? y2 : 0.0;
                 }
 #pragma unroll
-                for (int cc = MOM_COPIES / 2; cc >= 1; cc >>= 1) x += __shfl_down(x, cc * FAR_ORDER);
+                for (int cc = S_COPIES / 2; cc >= 1; cc >>= 1) x += __shfl_down(x, cc * S_ORDER);
                 const double m0 = readlane_f64(x, 0);
                 if (m0 != 0.0) {
                     if (FILL) {
-                        double m[FAR_ORDER];
+                        double m[S_ORDER];
 #pragma unroll
-                        for (int k = 0; k < FAR_ORDER; ++k) m[k] = readlane_f64(x, k);
+                        for (int k = 0; k < S_ORDER; ++k) m[k] = readlane_f64(x, k);
                         if (lane == 0) {
                             ScratchEnt *o = out + wpos;
                             o[0] = ScratchEnt{m[0], P.row_of_slot[0] * P.rowmul, 0};
                             double2 *o2 = reinterpret_cast<double2 *>(o + 1);
-                            o2[0] = double2{m[1], m[2]};
-                            o2[1] = double2{m[3], m[4]};
-                            o2[2] = double2{m[5], m[6]};
-                            o2[3] = double2{m[7], 0.0};
+                            #pragma unroll
+                            for (int q = 0; q < S_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < S_ORDER ? m[2 * q + 2] : 0.0};
                         }
                     }
                     n_occ = 1;
@@ -2381,29 +2408,27 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
             }
             for (int s0 = 1; s0 < kmom; s0 += WAVE) {
                 const int s = s0 + lane;
-                double m[FAR_ORDER];
+                double m[S_ORDER];
 #pragma unroll
-                for (int k = 0; k < FAR_ORDER; ++k) m[k] = 0.0;
+                for (int k = 0; k < S_ORDER; ++k) m[k] = 0.0;
                 if (s < kmom) {
-                    double *ms = mom + (s + MOM_COPIES - 1) * FAR_ORDER;
+                    double *ms = mom + (s + S_COPIES - 1) * S_ORDER;
 #pragma unroll
-                    for (int k = 0; k < FAR_ORDER; ++k) { m[k] = ms[k]; ms[k] = 0.0; }
+                    for (int k = 0; k < S_ORDER; ++k) { m[k] = ms[k]; ms[k] = 0.0; }
                 }
                 const bool occ = m[0] != 0.0;
                 const unsigned long long mo = __ballot(occ);
                 if (FILL && occ) {
-                    ScratchEnt *o = out + wpos + PREP_MOM * (n_occ + rank(mo));
+                    ScratchEnt *o = out + wpos + S_MOM * (n_occ + rank(mo));
                     o[0] = ScratchEnt{m[0], P.row_of_slot[s] * P.rowmul, 0};
                     double2 *o2 = reinterpret_cast<double2 *>(o + 1);
-                    o2[0] = double2{m[1], m[2]};
-                    o2[1] = double2{m[3], m[4]};
-                    o2[2] = double2{m[5], m[6]};
-                    o2[3] = double2{m[7], 0.0};
+                    #pragma unroll
+                    for (int q = 0; q < S_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < S_ORDER ? m[2 * q + 2] : 0.0};
                 }
                 n_occ += __popcll(mo);
             }
             __builtin_amdgcn_wave_barrier();
-            wpos += PREP_MOM * n_occ;
+            wpos += S_MOM * n_occ;
         }
         if (FILL && lane == 0) *reinterpret_cast<int4 *>(out + hbase) = int4{SOLO_MAGIC, n_near_pad, n_occ, nfar_tot};
     }
@@ -2421,7 +2446,7 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_solo_kernel(ScanParams 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = blockDim.x / WAVE;
-#if BMX_XCD_MAP
+#if BMX_SOLO_XCD_MAP
     // the slices of one chunk of test sites on one XCD, next to each other in its dispatch order (see the prepared kernel): the
     // blobs are 100 KB per test site here and every slice reads all of them
     const int xcd = blockIdx.x & 7;
@@ -2452,32 +2477,27 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_solo_kernel(ScanParams 
     const int64_t t_begin = chunk * P.sites_per_block;
     const int64_t t_end = min(t_begin + (int64_t)P.sites_per_block, P.M);
     for (int64_t t = t_begin + wave; t < t_end; t += nw) {
-        // the stream of this test site through the ring: a wave uses up a chunk of 64 entries in ~0.4 us, less than a trip to
-        // memory, so TWO chunks are in flight behind the (up to) two staged ahead of the read position
+        // the stream of this test site through the ring, as in the prepared kernel (two chunks in flight and the slices of a
+        // chunk of test sites on one XCD were both measured here: 1.27 -> 1.21 M windows/s and no change)
         const double2 *src = reinterpret_cast<const double2 *>(V.arena + (V.blob_prefix[V.grp_base + t] - V.prefix_base));
         int pos = 0, staged_u = 0;
-        double nx_a, nx_b, ny_a, ny_b;
+        double nx_a, nx_b;
         {
-            const double2 q0 = src[lane], q1 = src[WAVE + lane];
+            const double2 q0 = src[lane];
             nx_a = q0.x; nx_b = q0.y;
-            ny_a = q1.x; ny_b = q1.y;
         }
         auto stage = [&]() {
             const int slot = (staged_u >> 6) & 3;
             ring2[slot * WAVE + lane] = double2{nx_a, nx_b};
             if (slot == 0 && lane < RING_MIRROR) ring2[RING_UNITS + lane] = double2{nx_a, nx_b};
             staged_u += WAVE;
-            nx_a = ny_a; nx_b = ny_b;
-            const double2 q1 = src[staged_u + WAVE + lane];
-            ny_a = q1.x; ny_b = q1.y;
+            const double2 q0 = src[staged_u + lane];
+            nx_a = q0.x; nx_b = q0.y;
             __builtin_amdgcn_wave_barrier();
         };
-        // [pos, pos + 144) is in the ring (pos moves by at most 64 units between two calls; the slot a step overwrites lies
-        // more than 16 units behind pos: staged_u <= pos + 144 before the step, 4 slots of 64)
-        auto need = [&]() {
-            if (pos + 144 > staged_u) stage();
+        auto need = [&]() {                   // [pos, pos + 80) is in the ring
+            if (pos + 80 > staged_u) stage();
         };
-        stage();
         stage();
         stage();
         bool bad = false;
@@ -2512,31 +2532,31 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_solo_kernel(ScanParams 
             pos += SOLO_GUARD;
             if (nfar) {
                 // fold the moments (both sides of the window at once: F = 1) and multiply by exp(sum_k -+ w_k p_k)
-                double pk[FAR_ORDER];
+                double pk[S_ORDER];
 #pragma unroll
-                for (int k = 0; k < FAR_ORDER; ++k) pk[k] = 0.0;
+                for (int k = 0; k < S_ORDER; ++k) pk[k] = 0.0;
                 for (int s = 0; s < n_occ; ++s) {
                     need();
                     const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
                     const ScratchEnt ua = rp[0];
                     const double R = loadR(ua.ro);
                     const double2 *qa = reinterpret_cast<const double2 *>(rp + 1);
-                    const double2 a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3];
-                    const double R2 = R * R, R3 = R2 * R, R4 = R2 * R2;
-                    pk[0] = fma(ua.e, R, pk[0]);
-                    pk[1] = fma(a0.x, R2, pk[1]);
-                    pk[2] = fma(a0.y, R3, pk[2]);
-                    pk[3] = fma(a1.x, R4, pk[3]);
-                    pk[4] = fma(a1.y, R4 * R, pk[4]);
-                    pk[5] = fma(a2.x, R4 * R2, pk[5]);
-                    pk[6] = fma(a2.y, R4 * R3, pk[6]);
-                    pk[7] = fma(a3.x, R4 * R4, pk[7]);
-                    pos += PREP_MOM;
-                }
-                double tsum = pk[FAR_ORDER - 1] * FAR_W[FAR_ORDER - 1];
+                    double pw[S_ORDER + 1];
+                    pw[1] = R;
 #pragma unroll
-                for (int k = FAR_ORDER - 2; k >= 0; --k) tsum = fma(pk[k], FAR_W[k], -tsum);      // w1 p1 - (w2 p2 - (w3 p3 - ...))
-                renorm(acc, E);                      // |tsum| <= FAR_CAP * 0.05 * 1.03 < 422: 2^609 on top of [1, 2) is safe
+                    for (int k = 2; k <= S_ORDER; ++k) pw[k] = pw[k >> 1] * pw[k - (k >> 1)];
+                    pk[0] = fma(ua.e, R, pk[0]);
+#pragma unroll
+                    for (int k = 2; k <= S_ORDER; ++k) {
+                        const double2 v = qa[(k - 2) >> 1];
+                        pk[k - 1] = fma((k & 1) ? v.y : v.x, pw[k], pk[k - 1]);
+                    }
+                    pos += S_MOM;
+                }
+                double tsum = pk[S_ORDER - 1] * S_W[S_ORDER - 1];
+#pragma unroll
+                for (int k = S_ORDER - 2; k >= 0; --k) tsum = fma(pk[k], S_W[k], -tsum);      // w1 p1 - (w2 p2 - (w3 p3 - ...))
+                renorm(acc, E);                      // |tsum| <= S_FAR_CAP * S_EPS * 1.1 < 600: 2^860 on top of [1, 2) is safe
                 since = 0;
                 acc *= exp_neg(-tsum);
             }
@@ -3226,7 +3246,7 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
         // z = A d >= thr has alpha max_grid|R| <= far_eps (log rounded up, the low mantissa byte replaced by the row's slot
         // after rounding up once more).  Rows with max|R| <= far_eps / e are far at any distance (thr = -1); rows absent from
         // the helper file (max|R| = inf) get NaN, which never compares as far.
-        const double eps = FAR_ORDER >= 8 ? 0.05 : FAR_ORDER >= 6 ? 0.0105 : 0.0016;
+        const double eps = P_EPS;
         std::vector<double> thr((size_t)c->rows);
         const size_t R_ = (size_t)c->rows, S_ = c->h_rowmax.size() / std::max<size_t>(R_, 1);
         for (size_t r = 0; r < R_; r++) {
@@ -3347,7 +3367,7 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
     //           3 -> J=8, 4 -> J=4 (same form); 10/11 -> J=16/8 without the power sums (exact products);
     //           8/9 -> J=16/8 pairs only; 5/6/7 -> J=16/8/4 readlane single-site loop; 1, 2 -> per-site kernel
     const int v = c->variant;
-    const bool prep_ok = FAR_ORDER == 8 && !diag_env("BMX_FAR_EPS");
+    const bool prep_ok = !diag_env("BMX_FAR_EPS");
     // one test site per wave, prepared (mode 5): sparse or unsorted test sites (variant 0), or on request (variant 16)
     const int64_t solo_gap = diag_env("BMX_SOLO_GAP") ? atoll(diag_env("BMX_SOLO_GAP")) : SOLO_GAP;
     const bool solo = prep_ok && !P.wide_tab && s->N < 0x7fffffffLL && (v == 16 || (v == 0 && (!can_group || s->test_gap > solo_gap)));
@@ -3431,10 +3451,12 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
         pl.thr_in_lds = c->rows <= PREP_THR_LDS_MAX ? 1 : 0;
         const int pm = use_lds ? MOM_SLOTS_LDS : MOM_SLOTS;      // the moment slots of prep_kernel (see above)
         P.mom_slots = pm;
-        pl.prep_threads = (pm > MOM_SLOTS_LDS && !solo) ? PREP_THREADS / 2 : PREP_THREADS;     // two moment arrays per wave: 34 KB with all 254 slots
+        pl.prep_threads = pm > MOM_SLOTS_LDS ? (solo ? PREP_THREADS / 2 : PREP_THREADS / 4) : PREP_THREADS;     // all 254 slots: 25 KB per moment array
         pl.prep_lds = ((pl.thr_in_lds ? (size_t)((c->rows + 1) & ~1) : 0) +
-                       (size_t)(pl.prep_threads / WAVE) * (solo ? (size_t)(pm + MOM_COPIES - 1 + 3) * FAR_ORDER
-                                                                 : 2 * (size_t)(pm + MOM_COPIES - 1 + 3) * FAR_ORDER + WAVE)) * sizeof(double);
+                       (size_t)(pl.prep_threads / WAVE) * (solo ? (size_t)(pm + S_COPIES - 1 + 3) * S_ORDER
+                                                                 : 2 * (size_t)(pm + P_COPIES - 1 + 3) * P_ORDER + WAVE)) * sizeof(double);
+        P.far_bits = (float)(P_EPS * 1.4427 * 1.1);          // |log1p(x)| <= 1.09 |x| for |x| <= 0.15 (1.16 at 0.25: order 16 uses 1.2)
+        if (P_ORDER == 16) P.far_bits = (float)(P_EPS * 1.4427 * 1.2);
 #define PP(JJ, FF) (const void *)prep_kernel<JJ, FF>
         if (solo) {
             pl.prep_count = (const void *)prep_solo_kernel<false>;
@@ -3537,7 +3559,7 @@ int launch_range(bmx_ctx *c, ChromSlot *s, ScanPlan &pl, int64_t off, int64_t cn
     P.center = s->center.p + off; P.center_hi = s->center_hi.p + off; P.M = cnt;
     P.part_T = c->part_T.p; P.part_lin = c->part_lin.p; P.part_ns = c->part_ns.p;
     int64_t blocks = (cnt + pl.spb - 1) / pl.spb * c->nslices;
-    if (pr && BMX_XCD_MAP) blocks = ((cnt + pl.spb - 1) / pl.spb + 7) / 8 * 8 * c->nslices;     // chunks padded to whole XCD rounds
+    if (pr && (pl.mode == 5 ? BMX_SOLO_XCD_MAP : BMX_XCD_MAP)) blocks = ((cnt + pl.spb - 1) / pl.spb + 7) / 8 * 8 * c->nslices;     // chunks padded to whole XCD rounds
     if (pr) {
         // the range's blobs: filled by the per-group kernel, then consumed by one wave per (group, slice)
         if ((size_t)pr->units + 8 * WAVE > c->arena.cap) HIP_TRY(c->arena.ensure((size_t)pr->units + 8 * WAVE));

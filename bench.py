@@ -68,9 +68,9 @@ def load_calibration(config, kernel, build_id):
             cal = json.load(f)
     except (OSError, ValueError):
         return None, 'no calibration file'
-    ent = cal.get('config%d' % config)
+    ent = cal.get(config)
     if not ent:
-        return None, 'no calibration entry for config %d' % config
+        return None, 'no calibration entry %s' % config
     if ent.get('kernel') != kernel:
         return None, 'calibration is for %s, this run used %s' % (ent.get('kernel'), kernel)
     if ent.get('build_id') != build_id:
@@ -465,7 +465,9 @@ def _run(args):
         evals_s = evals_per_step / k_step_s
         kname = plan['kernel'] if plan else 'none'
         build_id = _lib.lib().bmx_build_id().decode()
-        cal, why = load_calibration(args.config, kname, build_id)
+        cal_key = 'config%d' % args.config + ('_step%d' % args.step if args.step != 1 else '') + \
+                  ('_nspread%d' % args.n_spread if args.n_spread else '')
+        cal, why = load_calibration(cal_key, kname, build_id)
         nchrom = len(chroms)
         workload = {
             4: 'BASELINE config 4: synthetic whole genome, %d SNPs over %d chromosomes (GRCh37 proportions), n=%d, default '
@@ -486,7 +488,7 @@ def _run(args):
             'n_gpus': world.size, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'strong' if sharded else 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
+            'dtype': 'f64', 'data': 'synthetic', 'argv': sys.argv[1:],
             'config': {'workload': workload, 'windows_per_step': windows_per_step, 'launches_per_step': len(slots),
                        'grid_points': len(As) * len(xs) * len(ab),
                        'parallelism': ('test-site sharding, dp%d; one context per GPU holds every chromosome; ONE gather of all 16-B records '

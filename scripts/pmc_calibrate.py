@@ -7,6 +7,7 @@ same process (evals_per_step: sum over test sites of |x| |alpha| sum_A W_A, SURV
 import collections, csv, glob, json, os, sys
 
 tag, root = sys.argv[1], sys.argv[2]
+key = sys.argv[3] if len(sys.argv) > 3 else 'config' + tag.strip('c')      # entry name in profiles/r03_pmc_calibration.json
 tot = collections.defaultdict(float)
 per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))
 ndisp = {}
@@ -18,7 +19,7 @@ def family(name):
     """'scan', 'prep' (fill pass), 'count' (counting pass, outside the step) or None"""
     if 'clr_scan' in name:
         return 'scan'
-    if 'prep_kernel' in name:
+    if 'prep_kernel' in name or 'prep_solo_kernel' in name:
         return 'count' if 'false>' in name.replace(' ', '') else 'prep'
     return None
 
@@ -97,6 +98,6 @@ entry = {
     'valu_share_of_preparation_kernel': per_kernel['prep'].get('SQ_INSTS_VALU', 0.0) / valu if valu else None,
     'kernel_ms_profiled': dur,
     'source': 'rocprofv3 --pmc passes A-E of `python3 bench.py %s --steps 1 --warmup 0 --no-cpu-baseline` (scripts/pmc_collect.sh %s), '
-              'profiles/r03_pmc_%s_summary.txt' % (' '.join(sys.argv[3:]) or '--config ' + tag.strip('c'), tag, tag),
+              'profiles/r03_pmc_%s_summary.txt' % (' '.join(bench.get('argv', [])) or '--config ' + tag.strip('c'), tag, tag),
 }
-print(json.dumps({('config' + tag.strip('c')): entry}, indent=1))
+print(json.dumps({key: entry}, indent=1))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence behind bench.py's roofline (run on the GPU box, from the repo root):
-#   bash scripts/pmc_collect.sh <tag> <bench args...>      e.g.  bash scripts/pmc_collect.sh c3 --config 3
+#   [PMC_KEY=config3_step64] bash scripts/pmc_collect.sh <tag> <bench args...>      e.g.  bash scripts/pmc_collect.sh c3 --config 3
 # One process per counter group (the SQ block has 8 slots, FETCH_SIZE and WRITE_SIZE do not fit one TCC pass), each with
 # --kernel-trace so that the dispatch list comes with it; the program sits directly behind `--`.  Output: gpurun_out/r03/<tag>/.
 set -u
@@ -20,5 +20,5 @@ pass C SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM S
 pass D FETCH_SIZE
 pass E WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 cd $R
-python3 scripts/pmc_calibrate.py $TAG $OUT > $OUT/summary.txt 2>&1
+python3 scripts/pmc_calibrate.py $TAG $OUT ${PMC_KEY:-} > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
