@@ -2253,7 +2253,8 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
 // moments and takes one exp per A.  The round-2 per-site kernel did the walk (loads, exp, window test) in all eight slice
 // waves and multiplied every site of the window.
 //   blob(test site) = for iA: header (1 unit) {magic, n_near (multiple of 4), n_occ, n_far}; n_near entries (E, row offset);
-//                     4 guard entries; n_occ moment entries of 5 units
+//                     4 guard entries; n_occ moment entries of 5 units: (c_1, row offset) (c_2, c_3) ... with c_k = -+ w_k M_k, the
+//                     series' coefficient already in (with F = 1 the far field of a row is one polynomial in R)
 constexpr int SOLO_MAGIC = 0x50100000;
 constexpr int SOLO_GUARD = 4;
 // Far field of the solo kernels: order 8 on |x| <= 0.05 (the round-2 series).  With one test site per wave the fold of the moments
@@ -2261,7 +2262,7 @@ constexpr int SOLO_GUARD = 4;
 // (1.27 -> 1.14 M windows/s at stride 64) while it is faster for groups of 16.  The per-row thresholds on the device are
 // those of the grouped kernels (P_EPS): a site is far here S_SHIFT = log(P_EPS / S_EPS) later.
 constexpr int S_ORDER = 8, S_COPIES = 8, S_MOM = 1 + S_ORDER / 2, S_FAR_CAP = 8192;
-constexpr double S_EPS = 0.05;
+// (S_EPS = 0.05)
 constexpr double S_SHIFT = P_ORDER == 16 ? 1.6095 : P_ORDER == 12 ? 1.0987 : 0.0;
 __device__ constexpr double S_W[8] = {0.9999999999998467, 0.4999999999996164, 0.3333333341509627, 0.25000000122701976,
                                       0.19999882322703955, 0.16666529319200146, 0.1434841013671569, 0.12562715480255862};
@@ -2394,7 +2395,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
                     if (FILL) {
                         double m[S_ORDER];
 #pragma unroll
-                        for (int k = 0; k < S_ORDER; ++k) m[k] = readlane_f64(x, k);
+                        for (int k = 0; k < S_ORDER; ++k) m[k] = readlane_f64(x, k) * ((k & 1) ? -S_W[k] : S_W[k]);     // c_k = -+ w_k M_k
                         if (lane == 0) {
                             ScratchEnt *o = out + wpos;
                             o[0] = ScratchEnt{m[0], P.row_of_slot[0] * P.rowmul, 0};
@@ -2418,6 +2419,10 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
                 }
                 const bool occ = m[0] != 0.0;
                 const unsigned long long mo = __ballot(occ);
+                if (FILL) {
+#pragma unroll
+                    for (int k = 0; k < S_ORDER; ++k) m[k] *= (k & 1) ? -S_W[k] : S_W[k];
+                }
                 if (FILL && occ) {
                     ScratchEnt *o = out + wpos + S_MOM * (n_occ + rank(mo));
                     o[0] = ScratchEnt{m[0], P.row_of_slot[s] * P.rowmul, 0};
@@ -2531,31 +2536,25 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_solo_kernel(ScanParams 
             }
             pos += SOLO_GUARD;
             if (nfar) {
-                // fold the moments (both sides of the window at once: F = 1) and multiply by exp(sum_k -+ w_k p_k)
-                double pk[S_ORDER];
-#pragma unroll
-                for (int k = 0; k < S_ORDER; ++k) pk[k] = 0.0;
+                // With F = 1 the series collapses per row: log factor = sum_rows sum_k c_k R^k, c_k = -+ w_k M_k premultiplied by the
+                // preparation kernel -- one Horner chain in R per occupied row (both sides of the window at once)
+                double tsum = 0.0;
                 for (int s = 0; s < n_occ; ++s) {
                     need();
                     const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
                     const ScratchEnt ua = rp[0];
                     const double R = loadR(ua.ro);
                     const double2 *qa = reinterpret_cast<const double2 *>(rp + 1);
-                    double pw[S_ORDER + 1];
-                    pw[1] = R;
+                    double h = 0.0;
 #pragma unroll
-                    for (int k = 2; k <= S_ORDER; ++k) pw[k] = pw[k >> 1] * pw[k - (k >> 1)];
-                    pk[0] = fma(ua.e, R, pk[0]);
-#pragma unroll
-                    for (int k = 2; k <= S_ORDER; ++k) {
+                    for (int k = S_ORDER; k >= 2; --k) {
                         const double2 v = qa[(k - 2) >> 1];
-                        pk[k - 1] = fma((k & 1) ? v.y : v.x, pw[k], pk[k - 1]);
+                        h = fma(h, R, (k & 1) ? v.y : v.x);
                     }
+                    h = fma(h, R, ua.e);
+                    tsum = fma(h, R, tsum);
                     pos += S_MOM;
                 }
-                double tsum = pk[S_ORDER - 1] * S_W[S_ORDER - 1];
-#pragma unroll
-                for (int k = S_ORDER - 2; k >= 0; --k) tsum = fma(pk[k], S_W[k], -tsum);      // w1 p1 - (w2 p2 - (w3 p3 - ...))
                 renorm(acc, E);                      // |tsum| <= S_FAR_CAP * S_EPS * 1.1 < 600: 2^860 on top of [1, 2) is safe
                 since = 0;
                 acc *= exp_neg(-tsum);
