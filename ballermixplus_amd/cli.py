@@ -221,7 +221,9 @@ def main_many(opt, files, stamp=lambda what: None):
             data = InputData(files[i], opt.nofreq, opt.MAF, opt.nosub, opt.minCount, phys=opt.phys, Rrate=opt.Rrate)
             neut = NeutralSFS(opt.spectfile, opt.nofreq, opt.MAF, opt.nosub)
             neut.get_neut_probs(data)
-            nxt[i] = (data, neut)
+            # the host half of NormalizedBetaBinom (model arrays, every site's table row) here too: no device call
+            sel = engine.NormalizedBetaBinom(data, grid, opt.nofreq, opt.MAF, opt.nosub, device=device).prepare(neut)
+            nxt[i] = (data, neut, sel)
         except BaseException as e:          # incl. the reference-style sys.exit() of the readers: re-raised on the main thread
             nxt[i] = e
 
@@ -235,12 +237,11 @@ def main_many(opt, files, stamp=lambda what: None):
         got = nxt.pop(i)
         if isinstance(got, BaseException):
             raise got
-        data, neut = got
+        data, neut, sel = got
         if i + 1 < len(files):
             th = threading.Thread(target=host_stage, args=(i + 1,))
             th.start()
         say(f"\n{datetime.now()}. {infile} -> {outfile}")
-        sel = engine.NormalizedBetaBinom(data, grid, opt.nofreq, opt.MAF, opt.nosub, device=device)
         Scan(data, neut, sel, grid, outfile if world.rank == 0 else None, fixSize=opt.size, r=opt.w, s=opt.step, phys=opt.phys,
              noCenter=opt.noCenter, runner=runner, verbose=False, keep_results=False, reuse_ctx=ctx)
         ctx = sel.ctx

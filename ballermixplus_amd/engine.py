@@ -236,14 +236,8 @@ class NormalizedBetaBinom:
         its table and buffers are kept and only the site arrays are replaced."""
         if self._bound_to is NeutralSFS and self.ctx is not None:
             return self
+        self.prepare(NeutralSFS)
         d = self._data
-        if NeutralSFS is None:      # get() before any scan: neutral part is irrelevant to P_sel
-            spect = {(k, int(n)): 1.0 for n in d.sampSizes for k in range(int(n) + 1)}
-            props = {int(n): 1.0 for n in d.sampSizes}
-        else:
-            spect, props = NeutralSFS.spect, NeutralSFS.sampProps
-        self.model = ModelArrays(self.stat, d.minCount, d.sampSizes, spect, props, self.grid_x, self.grid_abeta)
-        self.rows = self.model.rows_of(d.count, d.total)
         if self.ctx is not None and self.ctx is not reuse:
             self.ctx.close()
         akey = tuple(float(a) for a in self.grid_A)
@@ -269,6 +263,22 @@ class NormalizedBetaBinom:
         self._psel = None
         return self
 
+    def prepare(self, NeutralSFS):
+        """The host half of bind(): the bmx_model arrays and every site's table row.  No device call, so a whole-genome run
+        does it for the next chromosome on a helper thread while the current one is scanned (cli.main_many)."""
+        if getattr(self, '_prepared_for', self) is NeutralSFS and getattr(self, 'model', None) is not None:
+            return self
+        d = self._data
+        if NeutralSFS is None:      # get() before any scan: neutral part is irrelevant to P_sel
+            spect = {(k, int(n)): 1.0 for n in d.sampSizes for k in range(int(n) + 1)}
+            props = {int(n): 1.0 for n in d.sampSizes}
+        else:
+            spect, props = NeutralSFS.spect, NeutralSFS.sampProps
+        self.model = ModelArrays(self.stat, d.minCount, d.sampSizes, spect, props, self.grid_x, self.grid_abeta)
+        self.rows = self.model.rows_of(d.count, d.total)
+        self._prepared_for = NeutralSFS
+        return self
+
     def get(self, x, a):
         """v1:362-363"""
         if self.ctx is None:
@@ -283,8 +293,9 @@ def scan_stream(sel, test_gen, win_lo, win_hi, outfile, phys, gen_label, fetch=T
     """scan_batch + the output rows appended to `outfile` while the scan runs (the reference writes as it scans,
     v1:599-608).  Returns what scan_batch returns (None with fetch=False: the file is all the caller wants)."""
     sel.ctx.set_tests(test_gen, win_lo, win_hi)
+    # chunks of 64k test sites keep the first rows early on small inputs; large inputs take 256k per chunk (fewer kernel tails)
     sel.ctx.scan_write(outfile, phys, gen_label, [f'{v}' for v in sel.grid_x], [f'{v}' for v in sel.grid_abeta],
-                       [f'{v}' for v in sel.grid_A])
+                       [f'{v}' for v in sel.grid_A], chunk=262144 if len(phys) >= (1 << 20) else 0)
     return sel.ctx.fetch() if fetch else None
 
 
