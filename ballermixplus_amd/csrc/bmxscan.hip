@@ -1433,8 +1433,11 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
         __syncthreads();
     }
     // per wave: the moments of the right and of the left zone of one A (the stream holds both zones' near lists before either
-    // zone's moments, so the right zone's sums wait while the left zone is walked), then 64 doubles of scratch
-    const int mom_len = (P.mom_slots + P_COPIES - 1 + 3) * P_ORDER;
+    // zone's moments, so the right zone's sums wait while the left zone is walked), then 64 doubles of scratch.  P.mom_slots
+    // is the largest number of slots any A uses (not the 64 / 254 the table would allow): LDS per wave decides how many waves
+    // of this latency-bound kernel a CU holds.  The counting pass keeps one occupancy flag per slot (MS = 1).
+    constexpr int MS = FILL ? P_ORDER : 1;
+    const int mom_len = (P.mom_slots + P_COPIES - 1 + 3) * MS;
     double *mom_r = lds_p + thr_len + wave * (2 * mom_len + WAVE);
     double *mom_l = mom_r + mom_len;
     double *ragscr = mom_l + mom_len;
@@ -1518,7 +1521,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                     if (FILL) Ev = bulk ? exp_neg(zn) : 0.0;
                     if (nfar) {
                         if (moml) {
-                            double *mr = mom + (slot ? slot + P_COPIES - 1 : (lane & (P_COPIES - 1))) * P_ORDER;
+                            double *mr = mom + (slot ? slot + P_COPIES - 1 : (lane & (P_COPIES - 1))) * MS;
                             if (FILL) {
                                 // a lane adds only the powers whose term can exceed 2e-15: x = alpha max|R| = far_eps exp(-(z - th))
                                 const double d = zn - th;
@@ -1533,7 +1536,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                                     atomicAdd(mr + (k - 1), Ek);
                                 }
                             } else {
-                                mom[(slot ? slot + P_COPIES - 1 : 0) * P_ORDER] = 1.0;      // occupancy only
+                                mom[(slot ? slot + P_COPIES - 1 : 0) * MS] = 1.0;      // occupancy only
                             }
                         }
                         nfar_tot += nfar;
@@ -1610,7 +1613,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                 __builtin_amdgcn_wave_barrier();
                 {   // slot 0: P_COPIES copies read lane-parallel (copy = lane / order, moment = lane % order) + the private sums
                     double x = 0.0;
-                    if (lane < P_COPIES * P_ORDER) {
+                    if (lane < P_COPIES * MS) {
                         x = mom[lane];
                         mom[lane] = 0.0;
                     }
@@ -1624,7 +1627,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                         x += lane == 0 ? y1 : lane == 1 ? y2 : 0.0;       // copy 0, orders 1 and 2
                     }
 #pragma unroll
-                    for (int c = P_COPIES / 2; c >= 1; c >>= 1) x += __shfl_down(x, c * P_ORDER);
+                    for (int c = P_COPIES / 2; c >= 1; c >>= 1) x += __shfl_down(x, c * MS);
                     const double m0 = readlane_f64(x, 0);
                     if (m0 != 0.0) {
                         if (FILL) {
@@ -1648,9 +1651,9 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
 #pragma unroll
                     for (int k = 0; k < P_ORDER; ++k) m[k] = 0.0;
                     if (s < kmom) {
-                        double *ms = mom + (s + P_COPIES - 1) * P_ORDER;
+                        double *ms = mom + (s + P_COPIES - 1) * MS;
 #pragma unroll
-                        for (int k = 0; k < P_ORDER; ++k) { m[k] = ms[k]; ms[k] = 0.0; }
+                        for (int k = 0; k < MS; ++k) { m[k] = ms[k]; ms[k] = 0.0; }
                     }
                     const bool occ = m[0] != 0.0;
                     const unsigned long long mo = __ballot(occ);
@@ -2778,7 +2781,7 @@ struct ScanPlan {
     int mode = 3;           // inner-loop form of the grouped kernel (0..3), 4: prepared pipeline
     // prepared pipeline (mode 4): the per-group kernel's two forms and its launch shape
     const void *prep_count = nullptr, *prep_fill = nullptr;
-    size_t prep_lds = 0;
+    size_t prep_lds = 0, prep_lds_count = 0;
     int thr_in_lds = 0, prep_threads = PREP_THREADS;
 };
 
@@ -2797,6 +2800,7 @@ struct ChromSlot {
     DevBuf<int> d_row_of_slot;
     int row_of_slot[MOM_SLOTS] = {0};
     int nslots = 0;              // rows ranked by frequency: row_of_slot[0 .. nslots)
+    int kmom_max = 0;            // the most slots any A uses
     // tests
     bool has_tests = false;
     int64_t M = 0;
@@ -3218,6 +3222,8 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
             while (k < nslots && k < kcap && (double)cnt[(size_t)s->row_of_slot[k]] / (double)N * nfar * gain > 30.0) k++;
             km[(size_t)a] = (uint8_t)k;
         }
+        s->kmom_max = 0;
+        for (int a = 0; a < c->nA; a++) s->kmom_max = std::max(s->kmom_max, (int)km[(size_t)a]);
         // the kernel reads max |R| and the slot of a row with one load: the slot sits in the low mantissa
         // byte of the (rounded up) maximum; +inf becomes NaN, which never compares as far
         std::vector<double> packed(c->h_rowmax.size());
@@ -3448,12 +3454,16 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
     pl.range = range;
     if (prepared || solo) {
         pl.thr_in_lds = c->rows <= PREP_THR_LDS_MAX ? 1 : 0;
-        const int pm = use_lds ? MOM_SLOTS_LDS : MOM_SLOTS;      // the moment slots of prep_kernel (see above)
+        // the moment slots of prep_kernel: 64 with the table in LDS, all of them otherwise (see above) -- but no more than any A
+        // uses: the moment arrays are most of that kernel's LDS, and LDS per wave decides how many of its waves a CU holds
+        const int pm = std::max(1, std::min(use_lds ? MOM_SLOTS_LDS : MOM_SLOTS, s->kmom_max));
         P.mom_slots = pm;
-        pl.prep_threads = pm > MOM_SLOTS_LDS ? (solo ? PREP_THREADS / 2 : PREP_THREADS / 4) : PREP_THREADS;     // all 254 slots: 25 KB per moment array
-        pl.prep_lds = ((pl.thr_in_lds ? (size_t)((c->rows + 1) & ~1) : 0) +
-                       (size_t)(pl.prep_threads / WAVE) * (solo ? (size_t)(pm + S_COPIES - 1 + 3) * S_ORDER
-                                                                 : 2 * (size_t)(pm + P_COPIES - 1 + 3) * P_ORDER + WAVE)) * sizeof(double);
+        const size_t mom_fill = solo ? (size_t)(pm + S_COPIES - 1 + 3) * S_ORDER : 2 * (size_t)(pm + P_COPIES - 1 + 3) * P_ORDER + WAVE;
+        const size_t mom_count = solo ? mom_fill : 2 * (size_t)(pm + P_COPIES - 1 + 3) + WAVE;      // grouped counting pass: one flag per slot
+        pl.prep_threads = mom_fill * sizeof(double) > 20480 ? PREP_THREADS / 4 : PREP_THREADS;          // (all 254 slots: 25 KB per moment array)
+        const size_t thr_b = pl.thr_in_lds ? (size_t)((c->rows + 1) & ~1) * sizeof(double) : 0;
+        pl.prep_lds = thr_b + (size_t)(pl.prep_threads / WAVE) * mom_fill * sizeof(double);
+        pl.prep_lds_count = thr_b + (size_t)(pl.prep_threads / WAVE) * mom_count * sizeof(double);
         P.far_bits = (float)(P_EPS * 1.4427 * 1.1);          // |log1p(x)| <= 1.09 |x| for |x| <= 0.15 (1.16 at 0.25: order 16 uses 1.2)
         if (P_ORDER == 16) P.far_bits = (float)(P_EPS * 1.4427 * 1.2);
 #define PP(JJ, FF) (const void *)prep_kernel<JJ, FF>
@@ -3466,7 +3476,7 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
         }
 #undef PP
         if (pl.prep_lds > (size_t)LDS_LIMIT_BYTES) return fail(BMX_E_LIMIT, "LDS budget of the preparation kernel exceeded");
-        HIP_TRY(hipFuncSetAttribute(pl.prep_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prep_lds));
+        HIP_TRY(hipFuncSetAttribute(pl.prep_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prep_lds_count));
         HIP_TRY(hipFuncSetAttribute(pl.prep_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prep_lds));
     }
     TRACE("scan plan: lds=%zu use_lds=%d span_hi=%d spb=%d J=%d threads=%d range=%lld mode=%d", lds_bytes, (int)use_lds, c->span_hi, spb, J, threads,
@@ -3502,7 +3512,7 @@ int ensure_prep(bmx_ctx *c, ChromSlot *s) {
     Q.g_begin = 0; Q.g_end = ngroups;
     const int gpw = pl.prep_threads / WAVE;
     void *kargs[] = {&Q};
-    HIP_TRY(hipLaunchKernel(pl.prep_count, dim3((unsigned)((ngroups + gpw - 1) / gpw)), dim3(pl.prep_threads), kargs, pl.prep_lds, c->stream));
+    HIP_TRY(hipLaunchKernel(pl.prep_count, dim3((unsigned)((ngroups + gpw - 1) / gpw)), dim3(pl.prep_threads), kargs, pl.prep_lds_count, c->stream));
     hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t *)s->blob_units.p, ngroups, s->blob_prefix.p);
     HIP_TRY(hipGetLastError());
     std::vector<int64_t> pre((size_t)ngroups + 1);
