@@ -327,3 +327,26 @@ def test_solo_pipeline_on_sparse_test_sets(step):
             assert np.array_equal(out[0][q][samp], ref[q])
         assert np.allclose(out[0][0][samp], ref[0], rtol=1e-9, atol=1e-12)
     ctx.close()
+
+
+def test_bench_rccl_path_with_one_rank():
+    """bench.py with the process group forced on for a single rank (BMX_FORCE_DIST=1, backend nccl = RCCL): the step packs the
+    records on the device, gathers them with RCCL to rank 0 and copies them to pinned memory -- the code path of an N-GPU run,
+    on the one GPU this box has; same checksum as the plain one-process run."""
+    import json
+    env = dict(os.environ, BMX_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29671')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'BMX_DIST_BACKEND', 'BMX_SINGLE_DEVICE'):
+        env.pop(k, None)
+    common = [sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '2', '--warmup', '1', '--total-snps', '400000', '--no-cpu-baseline']
+    r = subprocess.run(common, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and 'ONE gather' in d['config']['parallelism'] and d['config']['records_per_step'] == d['config']['windows_per_step']
+    env.pop('BMX_FORCE_DIST')
+    r1 = subprocess.run(common, capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith('{')][-1])
+    assert 'pinned host memory' in d1['config']['parallelism']
+    assert d1['config']['checksum_clr'] == pytest.approx(d['config']['checksum_clr'], rel=1e-12)
