@@ -350,3 +350,50 @@ def test_bench_rccl_path_with_one_rank():
     d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith('{')][-1])
     assert 'pinned host memory' in d1['config']['parallelism']
     assert d1['config']['checksum_clr'] == pytest.approx(d['config']['checksum_clr'], rel=1e-12)
+
+
+@pytest.mark.parametrize('step', [1, 5])
+def test_prepared_pipeline_with_hot_rows_for_large_tables(step):
+    """41 sample sizes per file (3321 table rows: too large for LDS, read from global memory): the prepared kernel keeps the 96
+    most frequent rows in LDS and prep_kernel sorts every near list into entries of those rows and of the others.  Against the
+    round-2 grouped kernel (same table path) on every test site and the C oracle on a sample; the plan says R comes from global
+    memory."""
+    from ballermixplus_amd import engine as eng, synth
+    from ballermixplus_amd.hostmodel import Grids
+    N, n, spread = 200000, 100, 40
+    phys, gen, k, nn = synth.synth_chromosome(N, n, 6)
+    rng = np.random.default_rng(11)
+    n2 = rng.integers(n - spread, n + 1, N)
+    k = np.where(k == nn, n2, np.maximum(1, np.minimum(n2 - 1, (k * n2) // nn)))
+    nn = n2
+    sizes = sorted(set(nn.tolist()))
+    cnt = {(a, b): f for a, b, f in synth.spect_from_counts(k, nn)}
+    props = {int(s_): float(sum(f for (a, b), f in cnt.items() if b == s_)) for s_ in sizes}
+    grid = Grids(None, None, False, False, None, None)
+    xs, ab, As = grid.scan_order()
+    model = eng.ModelArrays('B2', int(k.min()), sizes, cnt, props, xs, ab)
+    rows = model.rows_of(k, nn)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, rows)
+    M = 16384 // step
+    idx = 40000 + step * np.arange(M)
+    lo, hi = np.zeros(M, np.int64), np.full(M, N - 1, np.int64)
+    out = {}
+    for v in (0, 12):
+        ctx.set_variant(v)
+        ctx.set_tests(gen[idx], lo, hi)
+        pl = ctx.plan()
+        assert not pl['use_lds'] and pl['mode'] == (4 if v == 0 else 3)
+        ctx.scan()
+        out[v] = ctx.fetch()
+    for a, b in zip(out[0][1:], out[12][1:]):
+        assert np.array_equal(a, b)
+    assert np.max(np.abs(out[0][0] - out[12][0]) / np.maximum(np.abs(out[12][0]), 1e-9)) < 1e-10
+    _, R = ctx.fetch_lut()
+    samp = np.arange(0, M, max(1, M // 40))
+    ref = c_scan(c_oracle(), np.where(np.isfinite(R), R, 0.0), As, gen, rows, gen[idx[samp]], lo[samp], hi[samp])
+    for q in (1, 2, 3, 4):
+        assert np.array_equal(out[0][q][samp], ref[q])
+    assert np.allclose(out[0][0][samp], ref[0], rtol=1e-9, atol=1e-12)
+    ctx.close()
