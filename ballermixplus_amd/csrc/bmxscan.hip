@@ -290,7 +290,6 @@ struct ScanParams {
     int row_of_slot[MOM_SLOTS];
     int row0;          // per-site kernel: the most frequent row of the data (-1: none)
     int mom_slots;     // slots per wave allocated in LDS (<= MOM_SLOTS)
-    int hot_rows;      // prepared kernel with the table in global memory: this many of the most frequent rows are also in LDS
     int wide_tab;      // the global R table has 2^32 bytes or more
     unsigned long long *prof;   // -DBMX_PROFILE builds: cycles per kernel section, summed over waves (else unused)
     float far_bits;    // far_eps * log2(e): exponent-budget bits per far site
@@ -1346,13 +1345,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 //
 //   blob(group)  = for iA in 0..nA-1: near(iA, right), near(iA, left), far(iA, right), far(iA, left);   16-byte units,
 //                  padded to a multiple of 4
-//   near(zone)   = header (4 units): {magic | rag, n_pair, n_quad, n_occ} {n_far, n_rag, end index | ZONE_DONE, n_pair_cold}
-//                             {n_j bytes} {n_quad_cold, tag, -, -}
+//   near(zone)   = header (3 units): {magic | rag, n_pair, n_quad, n_occ} {n_far, n_rag, end index | ZONE_DONE, tag} {n_j bytes}
 //                  near list: n_pair entries with alpha > 1/2 (padded to whole blocks), then n_quad entries (multiple of 4),
 //                             each (E_i f64, row offset i32), in walk order; 8 neutral guard entries (what the block loops
-//                             request one block ahead).  With hot rows (table in global memory, the most frequent rows also in
-//                             LDS): pairs of hot rows, pairs of cold rows, quads of hot rows, quads of cold rows -- four lists,
-//                             each padded, so that no block mixes the two kinds of row reference
+//                             request one block ahead)
 //   far(zone)    = moments:   n_occ entries of 5 units: (M_1, row offset) (M_2, M_3) (M_4, M_5) (M_6, M_7) (M_8, -)
 //                  ragged end (rag only): n_rag entries (E, row offset) + 1 guard
 //   (both near lists first: the consumer multiplies, then takes ONE exp per test site for the two far fields together)
@@ -1392,8 +1388,7 @@ __device__ constexpr double P_W[8] = {0.9999999999998467, 0.4999999999996164, 0.
 __device__ constexpr double P_D[6] = {7.94, 5.13, 3.462, 2.357, 1.571, 0.985};
 #endif
 constexpr double P_RAG_D = P_ORDER == 16 ? 6.74 : P_ORDER == 12 ? 6.23 : 5.13;     // log(P_EPS / 3e-4): the ragged end's third-order test
-constexpr int PREP_HDR = 4, PREP_GUARD = 8, PREP_MOM = 1 + P_ORDER / 2, PREP_RAG_GUARD = 1;     // a moment entry: (M_1, row) + M_2 .. M_K in pairs
-constexpr int HOT_ROWS_MAX = 96;              // table too large for LDS: this many of the most frequent rows are kept there (48 KB per slice)
+constexpr int PREP_HDR = 3, PREP_GUARD = 8, PREP_MOM = 1 + P_ORDER / 2, PREP_RAG_GUARD = 1;     // a moment entry: (M_1, row) + M_2 .. M_K in pairs
 constexpr int PREP_MAGIC = 0x5a0e0000;
 constexpr int RING_UNITS = 256, RING_MIRROR = 32, AUX_UNITS = 32;     // per wave: ring of 4 x 64 units + 32 mirrored + scratch
 constexpr int PREP_ZONE_DONE = -0x7fffffff;
@@ -1406,8 +1401,6 @@ struct PrepParams {
     RowArray row;
     int64_t N;
     int rows, rowmul;             // consumer's row offset = row * rowmul (64: LDS slice, NP: global table)
-    int hot_rows;                 // > 0 (table read from global memory): rows ranked below this are ALSO in the consumer's LDS; their
-                                  // entries carry the LDS offset (rank * 64) and go to lists of their own
     const double *A;
     int nA;
     const double *test_gen;       // the slot's test sites (absolute indexing: group g = test sites [g J, g J + J))
@@ -1461,7 +1454,6 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
         return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
     };
     constexpr int BS = J >= 16 ? 4 : 8;             // sites per pair block of the consumer
-    const bool HOT = P.hot_rows > 0;
 
     // group prologue: the consumer's, value for value
     const int64_t tb = grp * J;
@@ -1493,43 +1485,11 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
         // One zone, first half: header slot, near list (pairs, then quads), guard; the far sites' moments go to `mom`; the
         // ragged end is sized.  What the second half needs comes back through the reference arguments.
         auto zone_near = [&](int base, int dir, double tnear, double tfar, double *mom, int &zbase_o, int &npp_o, int &nqp_o, int &nfar_o,
-                             int &base_o, double &m1p_o, double &m2p_o, int &nragv_o, int &nrmax_o, bool &rag_o, double &zr_o, int &rr_o,
-                             int &npc_o, int &nqc_o) {
+                             int &base_o, double &m1p_o, double &m2p_o, int &nragv_o, int &nrmax_o, bool &rag_o, double &zr_o, int &rr_o) {
             const int zbase = wpos, nbase = zbase + PREP_HDR;
             int n_pair = 0, n_pair_pad = 0, n_quad = 0, nfar_tot = 0, pad_ro = 0;
             bool pair_open = true, seen = false;
             double m1p = 0.0, m2p = 0.0;
-            // hot rows: the four lists' sizes first (a walk without exp, moments or stores), so that every entry has its place
-            int c_ph = 0, c_pc = 0, c_qh = 0, c_qc = 0;             // entries: pairs hot / cold, quads hot / cold
-            if (HOT) {
-                int nf = 0;
-                int i2 = base + dir * lane;
-                while (true) {
-                    const bool ok = dir > 0 ? (i2 <= hi_min) : (i2 >= lo_max);
-                    const int ic = min(max(i2, 0), N - 1);
-                    const double g = P.genpos[ic];
-                    const int rraw = (int)P.row[ic];
-                    const bool bulk = ok && (A * fabs(g - tfar) <= P.zcut);
-                    const int cnt = __popcll(__ballot(bulk));
-                    if (cnt) {
-                        const double zn = A * fabs(g - tnear);
-                        const double th = thr_of(rraw);
-                        const int slot = __double2loint(th) & 0xff;
-                        const bool moml = bulk && slot < kmom && zn >= th && nf < P_FAR_CAP;
-                        const bool nearl = bulk && !moml, hot = slot < P.hot_rows, pr = zn < LN2;
-                        nf += __popcll(__ballot(moml));
-                        c_ph += __popcll(__ballot(nearl && pr && hot));
-                        c_pc += __popcll(__ballot(nearl && pr && !hot));
-                        c_qh += __popcll(__ballot(nearl && !pr && hot));
-                        c_qc += __popcll(__ballot(nearl && !pr && !hot));
-                    }
-                    if (cnt < WAVE) break;
-                    i2 += dir * WAVE;
-                }
-            }
-            const int p_ph = (c_ph + BS - 1) & ~(BS - 1), p_pc = (c_pc + BS - 1) & ~(BS - 1), p_qh = (c_qh + 3) & ~3, p_qc = (c_qc + 3) & ~3;
-            int w_ph = 0, w_pc = 0, w_qh = 0, w_qc = 0;             // written so far
-            int pad_hot = 0;                                        // a valid row reference of either kind for the padding
             auto close_pairs = [&]() {
                 n_pair_pad = (n_pair + BS - 1) & ~(BS - 1);
                 if (FILL && lane < n_pair_pad - n_pair) out[nbase + n_pair + lane] = ScratchEnt{0.0, pad_ro, 0};
@@ -1559,18 +1519,6 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                     if (!seen) { pad_ro = __builtin_amdgcn_readlane(rraw, 0) * P.rowmul; seen = true; }   // lane 0: a site of the zone
                     double Ev = 0.0;
                     if (FILL) Ev = bulk ? exp_neg(zn) : 0.0;
-                    if (HOT) {
-                        // each near entry to its list: [pairs hot][pairs cold][quads hot][quads cold], each already sized
-                        const bool hot = slot < P.hot_rows;
-                        const unsigned long long m_ph = __ballot(pairl && hot), m_pc = __ballot(pairl && !hot),
-                                                 m_qh = __ballot(nearl && !pairl && hot), m_qc = __ballot(nearl && !pairl && !hot);
-                        if (FILL && nearl) {
-                            const int at = pairl ? (hot ? w_ph + rank(m_ph) : p_ph + w_pc + rank(m_pc))
-                                                 : (hot ? p_ph + p_pc + w_qh + rank(m_qh) : p_ph + p_pc + p_qh + w_qc + rank(m_qc));
-                            out[nbase + at] = ScratchEnt{Ev, hot ? slot * WAVE : rraw * P.rowmul, 0};
-                        }
-                        w_ph += __popcll(m_ph); w_pc += __popcll(m_pc); w_qh += __popcll(m_qh); w_qc += __popcll(m_qc);
-                    }
                     if (nfar) {
                         if (moml) {
                             double *mr = mom + (slot ? slot + P_COPIES - 1 : (lane & (P_COPIES - 1))) * MS;
@@ -1593,12 +1541,12 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                         }
                         nfar_tot += nfar;
                     }
-                    if (!HOT && pair_open) {
+                    if (pair_open) {
                         if (FILL && pairl) out[nbase + n_pair + rank(mp)] = ScratchEnt{Ev, rraw * P.rowmul, 0};
                         n_pair += __popcll(mp);
                         if (__ballot(bulk && !(zn < LN2)) != 0ull || cnt < WAVE) close_pairs();
                     }
-                    if (!HOT && !pair_open) {
+                    if (!pair_open) {
                         if (FILL && nearl && !pairl) out[nbase + n_pair_pad + n_quad + rank(mq)] = ScratchEnt{Ev, rraw * P.rowmul, 0};
                         n_quad += __popcll(mq);
                     }
@@ -1607,30 +1555,13 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                 if (cnt < WAVE) break;
                 i = inx;
             }
-            int n_quad_pad;
-            if (HOT) {
-                // padding of the four lists and the guard: neutral entries whose row reference is of the list's kind (a hot
-                // list's padding points at LDS row 0, a cold list's at a row of the zone in the global table)
-                if (FILL) {
-                    if (lane < p_ph - c_ph) out[nbase + c_ph + lane] = ScratchEnt{0.0, 0, 0};
-                    if (lane < p_pc - c_pc) out[nbase + p_ph + c_pc + lane] = ScratchEnt{0.0, pad_ro, 0};
-                    if (lane < p_qh - c_qh) out[nbase + p_ph + p_pc + c_qh + lane] = ScratchEnt{0.0, 0, 0};
-                    if (lane < p_qc - c_qc) out[nbase + p_ph + p_pc + p_qh + c_qc + lane] = ScratchEnt{0.0, pad_ro, 0};
-                    if (lane < PREP_GUARD) out[nbase + p_ph + p_pc + p_qh + p_qc + lane] = ScratchEnt{0.0, 0, 0};
-                }
-                n_pair_pad = p_ph;
-                n_quad_pad = p_qh;
-                wpos = nbase + p_ph + p_pc + p_qh + p_qc + PREP_GUARD;
-            } else {
-                if (pair_open) close_pairs();
-                n_quad_pad = (n_quad + 3) & ~3;
-                if (FILL) {
-                    if (lane < n_quad_pad - n_quad) out[nbase + n_pair_pad + n_quad + lane] = ScratchEnt{0.0, pad_ro, 0};
-                    if (lane < PREP_GUARD) out[nbase + n_pair_pad + n_quad_pad + lane] = ScratchEnt{0.0, pad_ro, 0};
-                }
-                wpos = nbase + n_pair_pad + n_quad_pad + PREP_GUARD;
+            if (pair_open) close_pairs();
+            const int n_quad_pad = (n_quad + 3) & ~3;
+            if (FILL) {
+                if (lane < n_quad_pad - n_quad) out[nbase + n_pair_pad + n_quad + lane] = ScratchEnt{0.0, pad_ro, 0};
+                if (lane < PREP_GUARD) out[nbase + n_pair_pad + n_quad_pad + lane] = ScratchEnt{0.0, pad_ro, 0};
             }
-            (void)pad_hot;
+            wpos = nbase + n_pair_pad + n_quad_pad + PREP_GUARD;
 
             // ragged far end (see the grouped kernel): per-window counts n_j by bisection with the scan's own predicate
             int nrag_v = 0, nrmax = 0;
@@ -1673,11 +1604,10 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
             }
             zbase_o = zbase; npp_o = n_pair_pad; nqp_o = n_quad_pad; nfar_o = nfar_tot; base_o = base; m1p_o = m1p; m2p_o = m2p;
             nragv_o = nrag_v; nrmax_o = nrmax; rag_o = rag; zr_o = zr; rr_o = rr;
-            npc_o = HOT ? p_pc : 0; nqc_o = HOT ? p_qc : 0;
         };
         // ... second half: the moments of the occupied slots (slot order), the ragged end's entries, and the header
         auto zone_far = [&](double *mom, int zbase, int n_pair_pad, int n_quad_pad, int nfar_tot, int base, double m1p, double m2p,
-                            int nrag_v, int nrmax, bool rag, double zr, int rr, int tag, int n_pair_cold, int n_quad_cold) {
+                            int nrag_v, int nrmax, bool rag, double zr, int rr, int tag) {
             int n_occ = 0;
             if (nfar_tot) {
                 __builtin_amdgcn_wave_barrier();
@@ -1706,7 +1636,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                             for (int k = 0; k < P_ORDER; ++k) m[k] = readlane_f64(x, k);
                             if (lane == 0) {
                                 ScratchEnt *o = out + wpos;
-                                o[0] = HOT ? ScratchEnt{m[0], 0, 1} : ScratchEnt{m[0], P.row_of_slot[0] * P.rowmul, 0};      // (M_1, row reference, 1: LDS row)
+                                o[0] = ScratchEnt{m[0], P.row_of_slot[0] * P.rowmul, 0};
                                 double2 *o2 = reinterpret_cast<double2 *>(o + 1);
                                 #pragma unroll
                                 for (int q = 0; q < P_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < P_ORDER ? m[2 * q + 2] : 0.0};
@@ -1729,7 +1659,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                     const unsigned long long mo = __ballot(occ);
                     if (FILL && occ) {
                         ScratchEnt *o = out + wpos + PREP_MOM * (n_occ + rank(mo));
-                        o[0] = (HOT && s < P.hot_rows) ? ScratchEnt{m[0], s * WAVE, 1} : ScratchEnt{m[0], P.row_of_slot[s] * P.rowmul, 0};
+                        o[0] = ScratchEnt{m[0], P.row_of_slot[s] * P.rowmul, 0};
                         double2 *o2 = reinterpret_cast<double2 *>(o + 1);
                         #pragma unroll
                         for (int q = 0; q < P_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < P_ORDER ? m[2 * q + 2] : 0.0};
@@ -1741,10 +1671,8 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
             }
             if (rag) {
                 if (FILL) {
-                    const int rslot = __double2loint(thr_of(rr)) & 0xff;
-                    const bool rhot = HOT && rslot < P.hot_rows;
-                    if (lane < nrmax) out[wpos + lane] = ScratchEnt{exp_neg(zr), rhot ? rslot * WAVE : rr * P.rowmul, rhot ? 1 : 0};
-                    if (lane == nrmax) out[wpos + lane] = ScratchEnt{0.0, rhot ? rslot * WAVE : rr * P.rowmul, rhot ? 1 : 0};
+                    if (lane < nrmax) out[wpos + lane] = ScratchEnt{exp_neg(zr), rr * P.rowmul, 0};
+                    if (lane == nrmax) out[wpos + lane] = ScratchEnt{0.0, rr * P.rowmul, 0};
                 }
                 wpos += nrmax + PREP_RAG_GUARD;
             }
@@ -1759,21 +1687,20 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                 if (lane == 0) {
                     int4 *o = reinterpret_cast<int4 *>(out + zbase);
                     o[0] = int4{PREP_MAGIC | (rag ? 1 : 0), n_pair_pad, n_quad_pad, n_occ};
-                    o[1] = int4{nfar_tot, rag ? nrmax : 0, rag ? PREP_ZONE_DONE : base, n_pair_cold};
+                    o[1] = int4{nfar_tot, rag ? nrmax : 0, rag ? PREP_ZONE_DONE : base, tag};
                     o[2] = int4{w0, w1, w2, w3};
-                    o[3] = int4{n_quad_cold, tag, 0, 0};
                 }
             }
         };
         // stream order: both zones' near lists, then both zones' far fields (the consumer multiplies first and takes ONE exp
         // per test site for the two far fields together)
-        int zbR, nppR, nqpR, nfR, beR, nrvR, nrmR, rrR, npcR, nqcR, zbL, nppL, nqpL, nfL, beL, nrvL, nrmL, rrL, npcL, nqcL;
+        int zbR, nppR, nqpR, nfR, beR, nrvR, nrmR, rrR, zbL, nppL, nqpL, nfL, beL, nrvL, nrmL, rrL;
         bool ragR, ragL;
         double m1R, m2R, zrR, m1L, m2L, zrL;
-        zone_near(R_int, +1, tL, t0, mom_r, zbR, nppR, nqpR, nfR, beR, m1R, m2R, nrvR, nrmR, ragR, zrR, rrR, npcR, nqcR);
-        zone_near(L_int - 1, -1, t0, tL, mom_l, zbL, nppL, nqpL, nfL, beL, m1L, m2L, nrvL, nrmL, ragL, zrL, rrL, npcL, nqcL);
-        zone_far(mom_r, zbR, nppR, nqpR, nfR, beR, m1R, m2R, nrvR, nrmR, ragR, zrR, rrR, iA * 2, npcR, nqcR);
-        zone_far(mom_l, zbL, nppL, nqpL, nfL, beL, m1L, m2L, nrvL, nrmL, ragL, zrL, rrL, iA * 2 + 1, npcL, nqcL);
+        zone_near(R_int, +1, tL, t0, mom_r, zbR, nppR, nqpR, nfR, beR, m1R, m2R, nrvR, nrmR, ragR, zrR, rrR);
+        zone_near(L_int - 1, -1, t0, tL, mom_l, zbL, nppL, nqpL, nfL, beL, m1L, m2L, nrvL, nrmL, ragL, zrL, rrL);
+        zone_far(mom_r, zbR, nppR, nqpR, nfR, beR, m1R, m2R, nrvR, nrmR, ragR, zrR, rrR, iA * 2);
+        zone_far(mom_l, zbL, nppL, nqpL, nfL, beL, m1L, m2L, nrvL, nrmL, ragL, zrL, rrL, iA * 2 + 1);
     }
     const int units = (wpos + 3) & ~3;
     if (!FILL) {
@@ -1840,13 +1767,6 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
         const int total = P.rows * WAVE;
         for (int idx = threadIdx.x; idx < total; idx += blockDim.x)
             lds_R[idx] = P.Rt[(size_t)(idx >> 6) * P.NP + slice * WAVE + (idx & 63)];
-    } else {
-        // table in global memory (many sample sizes): the most frequent rows of the data -- four fifths of the near-list
-        // entries -- are kept in LDS all the same; prep_kernel puts their entries into lists of their own (row reference =
-        // rank * 64), so no block of the loops below mixes LDS and global row references
-        const int total = P.hot_rows * WAVE;
-        for (int idx = threadIdx.x; idx < total; idx += blockDim.x)
-            lds_R[idx] = P.Rt[(size_t)P.row_of_slot[idx >> 6] * P.NP + slice * WAVE + (idx & 63)];
     }
     const char *Rb = reinterpret_cast<const char *>(P.Rt + slice * WAVE);
     const unsigned lane8 = (unsigned)lane * 8u;
@@ -1854,15 +1774,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
     auto loadR = [&](int rowoff) -> double {
         return USE_LDS ? lds_R[rowoff + lane] : *reinterpret_cast<const double *>(Rb + ((unsigned)rowoff * 8u + lane8));
     };
-    auto loadH = [&](int rowoff) -> double { return lds_R[rowoff + lane]; };                       // a row kept in LDS
-    // a row reference with its kind in the entry (moments, ragged ends): one uniform branch per entry
-    auto loadE = [&](const ScratchEnt &en) -> double {
-        if (USE_LDS) return lds_R[en.ro + lane];
-        double v;
-        if (__builtin_amdgcn_readfirstlane(en.pad)) v = lds_R[en.ro + lane]; else v = loadR(en.ro);
-        return v;
-    };
-    double *lds_tail = lds_R + (USE_LDS ? P.rows * WAVE : P.hot_rows * WAVE);
+    double *lds_tail = lds_R + (USE_LDS ? P.rows * WAVE : 0);
     constexpr int WAVE_UNITS = RING_UNITS + RING_MIRROR + AUX_UNITS;
     ScratchEnt *ring = reinterpret_cast<ScratchEnt *>(lds_tail) + wave * WAVE_UNITS;
     ScratchEnt *scr = ring + RING_UNITS + RING_MIRROR;              // 32 units of wave-private scratch
@@ -1871,7 +1783,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
     // the ring and the scratch start out as valid neutral entries (row offset 0): whatever is read ahead of the stream is a
     // legal row reference
     for (int idx = lane; idx < WAVE_UNITS; idx += WAVE) ring[idx] = ScratchEnt{0.0, 0, 0};
-    __syncthreads();
+    if (USE_LDS) __syncthreads(); else __builtin_amdgcn_wave_barrier();
 
     const int64_t ngroups = (P.M + J - 1) / J;
     const int64_t gpb = P.sites_per_block / J;
@@ -2028,17 +1940,15 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 }
                 need();
                 const int4 *hp = reinterpret_cast<const int4 *>(ring + (pos & (RING_UNITS - 1)));
-                const int4 h0 = hp[0], h1 = hp[1], h3 = hp[3];
+                const int4 h0 = hp[0], h1 = hp[1];
                 const int magic = __builtin_amdgcn_readfirstlane(h0.x);
                 const int n_pair = __builtin_amdgcn_readfirstlane(h0.y), n_quad = __builtin_amdgcn_readfirstlane(h0.z);
                 const int n_occ = __builtin_amdgcn_readfirstlane(h0.w);
                 const int nfar_tot = __builtin_amdgcn_readfirstlane(h1.x), nrmax = __builtin_amdgcn_readfirstlane(h1.y);
                 const int base_end = __builtin_amdgcn_readfirstlane(h1.z);
-                // table in global memory: n_pair / n_quad count the entries of the rows kept in LDS, these two the others'
-                const int n_pair_c = USE_LDS ? 0 : __builtin_amdgcn_readfirstlane(h1.w), n_quad_c = USE_LDS ? 0 : __builtin_amdgcn_readfirstlane(h3.x);
                 const bool rag = (magic & 1) != 0;
                 if ((magic & ~1) != PREP_MAGIC || n_pair < 0 || n_quad < 0 || n_pair > N + 8 || n_quad > N + 8 || n_occ < 0 || n_occ > MOM_SLOTS ||
-                    nrmax < 0 || nrmax >= WAVE || n_pair_c < 0 || n_quad_c < 0 || n_pair_c > N + 8 || n_quad_c > N + 8) {
+                    nrmax < 0 || nrmax >= WAVE) {
                     bad = true;
                     return PREP_ZONE_DONE;
                 }
@@ -2047,11 +1957,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 nocc_o = n_occ; nfar_o = nfar_tot; nrmax_o = nrmax; rag_o = rag;
                 pos += PREP_HDR;
 
-                // entries with alpha > 1/2, two per step; `load`: how a row reference becomes R (LDS or global), `pre`: rows of the
-                // NEXT block requested before this block's arithmetic (pays for global memory only)
-                auto pair_list = [&](int n, auto load, auto pre) {
-                    constexpr bool PRE = decltype(pre)::value;
-                    if (n <= 0) return;
+                if (n_pair > 0) {
                     need();
                     const double e0 = ring[pos & (RING_UNITS - 1)].e;       // the nearest site: the largest alpha of the list
                     const double om = 1.0 - e0, op = fma(e0, P.rmax, 1.0);
@@ -2059,34 +1965,34 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     const int pend_hi = ((__builtin_amdgcn_readfirstlane(__double2hiint(op)) >> 20) & 0x7ff) - 1022;
                     const int span8 = 8 * min(max(pend_hi, pend_lo), 125);
                     double Rp[BS], ep[BS];
-                    if (PRE) {
+                    if (BMX_PAIR_PREFETCH) {
                         const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
 #pragma unroll
                         for (int u = 0; u < BS; ++u) {
                             const ScratchEnt en = rp[u];
                             ep[u] = en.e;
-                            Rp[u] = load(en.ro);
+                            Rp[u] = loadR(en.ro);
                         }
                     }
-                    for (int l0 = 0; l0 < n; l0 += BS) {
+                    for (int l0 = 0; l0 < n_pair; l0 += BS) {
                         need();
                         const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
                         spend(span8 * BS / 8);
                         double v[BS];
-                        if (PRE) {
+                        if (BMX_PAIR_PREFETCH) {
 #pragma unroll
                             for (int u = 0; u < BS; ++u) v[u] = ep[u] * Rp[u];
 #pragma unroll
                             for (int u = 0; u < BS; ++u) {
                                 const ScratchEnt en = rp[BS + u];
                                 ep[u] = en.e;
-                                Rp[u] = load(en.ro);
+                                Rp[u] = loadR(en.ro);
                             }
                         } else {
 #pragma unroll
                             for (int u = 0; u < BS; ++u) {
                                 const ScratchEnt en = rp[u];
-                                v[u] = en.e * load(en.ro);
+                                v[u] = en.e * loadR(en.ro);
                             }
                         }
 #pragma unroll
@@ -2097,10 +2003,8 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         }
                         pos += BS;
                     }
-                };
-                // entries with alpha <= 1/2, four per step, the next block's entries and rows requested one block ahead
-                auto quad_list = [&](int n, auto load) {
-                    if (n <= 0) return;
+                }
+                if (n_quad > 0) {
                     need();
                     int span8q = 0;
                     double Rn[4], en_e[4];
@@ -2110,10 +2014,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         for (int u = 0; u < 4; ++u) {
                             const ScratchEnt en = rp[u];
                             en_e[u] = en.e;
-                            Rn[u] = load(en.ro);
+                            Rn[u] = loadR(en.ro);
                         }
                     }
-                    for (int l0 = 0; l0 < n; l0 += 4) {
+                    for (int l0 = 0; l0 < n_quad; l0 += 4) {
                         need();
                         const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
                         if ((l0 & 63) == 0) {
@@ -2130,7 +2034,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         for (int u = 0; u < 4; ++u) {
                             const ScratchEnt en = rp[4 + u];
                             en_e[u] = en.e;
-                            Rn[u] = load(en.ro);
+                            Rn[u] = loadR(en.ro);
                         }
                         const double s01 = v[0] + v[1], q01 = v[0] * v[1];
                         const double s23 = v[2] + v[3], q23 = v[2] * v[3];
@@ -2148,18 +2052,6 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         }
                         pos += 4;
                     }
-                };
-                if (USE_LDS) {
-                    pair_list(n_pair, loadH, std::false_type{});
-                    quad_list(n_quad, loadH);
-                } else {
-                    // stream order: pairs of LDS rows, pairs of global rows, quads of LDS rows, quads of global rows.  (What a loop
-                    // requests one block past its list is a reference of the other kind: an LDS read beyond the table returns 0,
-                    // a global read at a small offset stays inside the table; neither value is used.)
-                    pair_list(n_pair, loadH, std::false_type{});
-                    pair_list(n_pair_c, loadR, std::true_type{});
-                    quad_list(n_quad, loadH);
-                    quad_list(n_quad_c, loadR);
                 }
                 pos += PREP_GUARD;
                 return base_end;
@@ -2194,7 +2086,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
                     const bool two = s + 1 < n_occ;
                     const ScratchEnt ua = rp[0], ub = rp[two ? PREP_MOM : 0];
-                    const double Ra = loadE(ua), Rb2 = loadE(ub);
+                    const double Ra = loadR(ua.ro), Rb2 = loadR(ub.ro);
                     fold(ua.e, reinterpret_cast<const double2 *>(rp + 1), Ra);
                     if (two) fold(ub.e, reinterpret_cast<const double2 *>(rp + PREP_MOM + 1), Rb2);
                     pos += two ? 2 * PREP_MOM : PREP_MOM;
@@ -2207,7 +2099,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 if (rag) {
                     const ScratchEnt en = ring[pos & (RING_UNITS - 1)];
                     rag_e = en.e;
-                    rag_R = loadE(en);
+                    rag_R = loadR(en.ro);
                 }
 #pragma unroll
                 for (int w = 0; w < J; ++w) {
@@ -2218,7 +2110,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                             const double v = rag_e * rag_R, v2 = v * v;
                             const ScratchEnt en = ring[(pos + l + 1) & (RING_UNITS - 1)];     // one step ahead (the guard at the end)
                             rag_e = en.e;
-                            rag_R = loadE(en);
+                            rag_R = loadR(en.ro);
                             pk[0] += v;
                             pk[1] = fma(v2, 0.5, pk[1]);
                             pk[2] = fma(v2 * v, 0.3333333333333333, pk[2]);
@@ -3539,13 +3431,10 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
     // One wave per SIMD issues FP64 at half rate (measured), so a workgroup whose LDS footprint
     // allows only one resident workgroup per CU gets 8 waves instead of 4.
     int threads = SCAN_THREADS;
-    // prepared kernel with the table in global memory: the most frequent rows of the data are kept in LDS all the same
-    P.hot_rows = (prepared && !use_lds) ? std::min(s->nslots, HOT_ROWS_MAX) : 0;
-    const size_t lds_hot = (size_t)P.hot_rows * WAVE * sizeof(double);
-    size_t lds_bytes = (use_lds ? lds + (J ? lds_rm : 0) : lds_hot) + (J ? (size_t)(threads / WAVE) * wave_bytes(mom_slots) : 0);
+    size_t lds_bytes = (use_lds ? lds + (J ? lds_rm : 0) : 0) + (J ? (size_t)(threads / WAVE) * wave_bytes(mom_slots) : 0);
     if (J && 2 * lds_bytes > (size_t)LDS_LIMIT_BYTES) {
         threads = SCAN_THREADS_MAX;
-        lds_bytes = (use_lds ? lds + lds_rm : lds_hot) + (size_t)(threads / WAVE) * wave_bytes(mom_slots);
+        lds_bytes = (use_lds ? lds + lds_rm : 0) + (size_t)(threads / WAVE) * wave_bytes(mom_slots);
         spb *= 2;
     }
     if (!J) {       // per-site kernels: 16 waves, the R slice (if it fits) + 1 KB of scratch list (solo: 4.3 KB of ring) per wave
@@ -3599,7 +3488,6 @@ PrepParams prep_params(bmx_ctx *c, ChromSlot *s, const ScanPlan &pl) {
     PrepParams Q;
     Q.genpos = s->genpos.p; Q.row = pl.P.row; Q.N = s->N;
     Q.rows = c->rows; Q.rowmul = pl.use_lds ? WAVE : c->NP;
-    Q.hot_rows = pl.P.hot_rows;
     Q.A = c->d_A; Q.nA = c->nA;
     Q.test_gen = s->test_gen.p; Q.win_lo = s->win_lo.p; Q.win_hi = s->win_hi.p; Q.center = s->center.p; Q.center_hi = s->center_hi.p;
     Q.M = s->M; Q.zcut = c->zcut;

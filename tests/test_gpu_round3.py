@@ -353,11 +353,10 @@ def test_bench_rccl_path_with_one_rank():
 
 
 @pytest.mark.parametrize('step', [1, 5])
-def test_prepared_pipeline_with_hot_rows_for_large_tables(step):
-    """41 sample sizes per file (3321 table rows: too large for LDS, read from global memory): the prepared kernel keeps the 96
-    most frequent rows in LDS and prep_kernel sorts every near list into entries of those rows and of the others.  Against the
-    round-2 grouped kernel (same table path) on every test site and the C oracle on a sample; the plan says R comes from global
-    memory."""
+def test_prepared_pipeline_with_a_table_too_large_for_lds(step):
+    """41 sample sizes per file (3321 table rows: too large for LDS, read from global memory / L2) through the prepared
+    pipeline at J = 16 and J = 8: against the round-2 grouped kernel (same table path) on every test site and the C oracle
+    on a sample; the plan says R comes from global memory."""
     from ballermixplus_amd import engine as eng, synth
     from ballermixplus_amd.hostmodel import Grids
     N, n, spread = 200000, 100, 40
