@@ -1,28 +1,34 @@
 // bmxscan.hip -- libbmxscan.so: gfx950 kernels + C ABI (include/bmxscan.h).
 //
 // Hot path being replaced (reference BalLeRMix+_v1.py, "v1:LINE"):
-//   K1  bb_lut_kernel            <- NormalizedBetaBinom.__init__/get_raw_probs/get_*_normBase  v1:319-433
-//   K2  clr_scan_grouped_kernel  <- calcBaller, J test sites per wave (what ships)           v1:436-507
-//       clr_scan_kernel          <- calcBaller, one test site per wave (sparse test sets, fallback)
+//   K1  bb_lut_kernel              <- NormalizedBetaBinom.__init__/get_raw_probs/get_*_normBase  v1:319-433
+//   K2  prep_kernel + clr_scan_prepared_kernel    <- calcBaller, J = 16 / 8 test sites per wave-group (what ships for dense
+//                                     test sites; round 3)                                                  v1:436-507
+//       prep_solo_kernel + clr_scan_solo_kernel    <- calcBaller, one test site per wave (sparse or unsorted test sites)
+//       clr_scan_grouped_kernel, clr_scan_kernel  round 2's single-kernel forms: variants 12 / 2 (cross-checks in the
+//                                     tests), and the path for tables of 4 GiB and more
 //       locate_kernel / finalize_kernel: test-site positions, per-slice argmax merge + nSites
-//       surface_kernel           <- the full T[A,x,alpha] surface of one site (v1:449-450 wish)
+//       surface_kernel             <- the full T[A,x,alpha] surface of one site (v1:449-450 wish)
 //
 // The shipped library reads ONE environment variable, BMX_TRACE (stage messages on stderr, no effect on results).
-// Tuning knobs for A/B runs (BMX_LDS_PAD, BMX_DENSE_GAP, BMX_FORCE_J, BMX_FAR_EPS, BMX_MOM_SLOTS, BMX_SPB, BMX_ROWMAX_GLOBAL) exist only
-// in the diagnostic builds (-DBMX_DIAG: `make diag|prof|count`); the scan variant is chosen with bmx_ctx_set_variant().
+// Tuning knobs for A/B runs (BMX_LDS_PAD, BMX_DENSE_GAP, BMX_SOLO_GAP, BMX_FORCE_J, BMX_FAR_EPS, BMX_MOM_SLOTS, BMX_SPB,
+// BMX_ROWMAX_GLOBAL) exist only in the diagnostic builds (-DBMX_DIAG: `make diag|prof|count`); the scan variant is chosen with
+// bmx_ctx_set_variant().
 //
 // K2 formulation.  For a test site t and linkage value A the reference sums, over the sites
 // i of the window with alpha_i = exp(-A*|g_i - t|) >= 1e-8 and g_i != t (v1:454-457),
 //     log(alpha_i*S_i + (1-alpha_i)*g_i) - log(g_i)              (v1:494-499)
 // which equals log(1 + alpha_i*R[x,a][row_i]) with R = S*prop/g - 1 tabulated per (k,n) row.
-// The kernel keeps, per lane, the running PRODUCT  prod_i (1 + alpha_i*R)  (one FMA and one
+// The scan keeps, per lane, the running PRODUCT  prod_i (1 + alpha_i*R)  (one FMA and one
 // MUL per site and grid pair, no transcendental), pulls the binary exponent out of the product
 // every few sites so it cannot over/underflow, and takes a single log per (t, A, pair).
 // Lanes run over the (x, alpha_beta) pairs, so nothing is reduced across lanes until the
-// final argmax; alpha_i and row_i are computed lanes-over-sites and broadcast.
-// Far from the test sites (alpha*|R| <= 0.05: three quarters of a window) not even that: the sites'
+// final argmax.  Far from the test sites (alpha*|R| small: three quarters of a window) not even that: the sites'
 // alpha^k are added to per-row moments and the product picks up exp(sum_k +-w_k F^k sum_rows R^k M_k)
-// once per zone -- the log1p series to 8th order with economised coefficients (see clr_scan_grouped_kernel).
+// -- the log1p series with economised coefficients (order 12 on |x| <= 0.15 in the prepared kernels, order 8 on
+// |x| <= 0.05 in the solo and round-2 kernels).  Since round 3 everything that does not depend on the pair -- positions,
+// exp(-A d), the near / far decision, the moments, where each window ends -- is computed ONCE per group of test sites by a
+// lanes-over-sites kernel (prep_kernel) and streamed through HBM to the pair-parallel waves (see "K2, prepared" below).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -1638,7 +1644,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                                 ScratchEnt *o = out + wpos;
                                 o[0] = ScratchEnt{m[0], P.row_of_slot[0] * P.rowmul, 0};
                                 double2 *o2 = reinterpret_cast<double2 *>(o + 1);
-                                #pragma unroll
+#pragma unroll
                                 for (int q = 0; q < P_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < P_ORDER ? m[2 * q + 2] : 0.0};
                             }
                         }
@@ -1661,7 +1667,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                         ScratchEnt *o = out + wpos + PREP_MOM * (n_occ + rank(mo));
                         o[0] = ScratchEnt{m[0], P.row_of_slot[s] * P.rowmul, 0};
                         double2 *o2 = reinterpret_cast<double2 *>(o + 1);
-                        #pragma unroll
+#pragma unroll
                         for (int q = 0; q < P_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < P_ORDER ? m[2 * q + 2] : 0.0};
                     }
                     n_occ += __popcll(mo);
@@ -2403,7 +2409,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
                             ScratchEnt *o = out + wpos;
                             o[0] = ScratchEnt{m[0], P.row_of_slot[0] * P.rowmul, 0};
                             double2 *o2 = reinterpret_cast<double2 *>(o + 1);
-                            #pragma unroll
+#pragma unroll
                             for (int q = 0; q < S_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < S_ORDER ? m[2 * q + 2] : 0.0};
                         }
                     }
@@ -2430,7 +2436,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
                     ScratchEnt *o = out + wpos + S_MOM * (n_occ + rank(mo));
                     o[0] = ScratchEnt{m[0], P.row_of_slot[s] * P.rowmul, 0};
                     double2 *o2 = reinterpret_cast<double2 *>(o + 1);
-                    #pragma unroll
+#pragma unroll
                     for (int q = 0; q < S_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < S_ORDER ? m[2 * q + 2] : 0.0};
                 }
                 n_occ += __popcll(mo);
