@@ -348,7 +348,8 @@ def test_config4_whole_genome_on_one_context():
     (i) chromosomes 1, 12 and 22 equal a fresh context's run bitwise; (ii) every chromosome: all windows scanned, CLR
     finite and non-negative, nSites within the window bound, a checksum over (CLR, argmax) that a second pass reproduces
     for the three chromosomes of (i); (iii) the reference's own rows for the chromosomes it could afford
-    (tests/golden/synth/config4_chr{21,22}_step50000.tsv, made with the helper file of the whole genome)."""
+    (tests/golden/synth/config4_chr{21,22}_step50000.tsv, made with the helper file of the whole genome); (iv) chromosome 22 in
+    full through the round-2 kernel as well."""
     from ballermixplus_amd import engine as eng
     from ballermixplus_amd.hostmodel import Grids
     sizes, data, spect = _config4_data()
@@ -389,6 +390,15 @@ def test_config4_whole_genome_on_one_context():
         fresh.set_tests(gen, np.zeros(N, np.int64), np.full(N, N - 1, np.int64))
         fresh.scan()
         got = fresh.fetch()
+        if c == 22:
+            # (iv) the whole chromosome through the round-2 single-kernel form (variant 12): the two pipelines agree on the
+            # argmax and nSites of every one of its 712 415 windows, CLR to 1e-9
+            fresh.set_variant(12)
+            fresh.set_tests(gen, np.zeros(N, np.int64), np.full(N, N - 1, np.int64))
+            fresh.scan()
+            old = fresh.fetch()
+            assert all(np.array_equal(a, b) for a, b in zip(got[1:], old[1:]))
+            assert np.max(np.abs(got[0] - old[0]) / np.maximum(np.abs(old[0]), 1e-9)) < 1e-9
         fresh.close()
         assert all(np.array_equal(a, b) for a, b in zip(got, want)), c
     for cc in (21, 22):
