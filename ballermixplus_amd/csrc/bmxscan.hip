@@ -1351,11 +1351,13 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 //
 //   blob(group)  = for iA in 0..nA-1: near(iA, right), near(iA, left), far(iA, right), far(iA, left);   16-byte units,
 //                  padded to a multiple of 4
-//   near(zone)   = header (3 units): {magic | rag, n_pair, n_quad, n_occ} {n_far, n_rag, end index | ZONE_DONE, tag} {n_j bytes}
+//   near(zone)   = header (3 units): {magic | rag, n_pair, n_quad, n_occ} {n_far, n_rag, end index | ZONE_DONE, n_ser | class counts << 8} {n_j bytes}
 //                  near list: n_pair entries with alpha > 1/2 (padded to whole blocks), then n_quad entries (multiple of 4),
 //                             each (E_i f64, row offset i32), in walk order; 8 neutral guard entries (what the block loops
 //                             request one block ahead)
-//   far(zone)    = moments:   n_occ entries of 5 units: (M_1, row offset) (M_2, M_3) (M_4, M_5) (M_6, M_7) (M_8, -)
+//   far(zone)    = moments:   n_occ entries of PREP_MOM units: (M_1, row offset) (M_2, M_3) (M_4, M_5) ...
+//                  series entries: n_ser (a multiple of 4, <= 64) entries (E, row offset, order class) of far sites whose row has no
+//                                  moment slot, highest class first
 //                  ragged end (rag only): n_rag entries (E, row offset) + 1 guard
 //   (both near lists first: the consumer multiplies, then takes ONE exp per test site for the two far fields together)
 // Sizes come from a counting pass of the same code (prep_kernel<J, false>: identical predicates, no exp, no stores) run when
@@ -1395,6 +1397,12 @@ __device__ constexpr double P_D[6] = {7.94, 5.13, 3.462, 2.357, 1.571, 0.985};
 #endif
 constexpr double P_RAG_D = P_ORDER == 16 ? 6.74 : P_ORDER == 12 ? 6.23 : 5.13;     // log(P_EPS / 3e-4): the ragged end's third-order test
 constexpr int PREP_HDR = 3, PREP_GUARD = 8, PREP_MOM = 1 + P_ORDER / 2, PREP_RAG_GUARD = 1;     // a moment entry: (M_1, row) + M_2 .. M_K in pairs
+// Far sites of rows WITHOUT a moment slot (rare rows: fewer than ~1.3 sites per zone, so a slot's fold would cost more than it
+// saves): not multiplied either -- they go into the stream as "series entries" (E, row, order class) and the scan kernel adds
+// their (E R)^k to the same power sums p_k the moments feed, up to the order their alpha max|R| needs (2, 3, 5 or 8):
+// 3 to 9 instructions per entry for all 16 test sites, against 24.5 in the product form.  A third of the old near lists were such sites.
+constexpr double SER_DMIN = P_ORDER > 8 ? P_D[P_ORDER > 8 ? 6 : 0] : 0.0;      // order 9 and beyond below 2e-15
+constexpr int SER_CAP = 64;                  // series entries per zone (buffered in prep_kernel's LDS until the zone's far part is written)
 constexpr int PREP_MAGIC = 0x5a0e0000;
 constexpr int RING_UNITS = 256, RING_MIRROR = 32, AUX_UNITS = 32;     // per wave: ring of 4 x 64 units + 32 mirrored + scratch
 constexpr int PREP_ZONE_DONE = -0x7fffffff;
@@ -1418,6 +1426,7 @@ struct PrepParams {
     const uint8_t *kmom;
     const int *row_of_slot;       // [MOM_SLOTS]
     int mom_slots;
+    int ser_cap;       // series entries per zone (SER_CAP; diagnostic builds: BMX_SER_CAP, 0 = none)
     int64_t g_begin, g_end;       // groups of this launch
     int32_t *blob_units;          // counting pass: [groups of the slot]
     const int64_t *blob_prefix;   // fill pass: exclusive prefix of blob_units
@@ -1447,6 +1456,9 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
     double *mom_r = lds_p + thr_len + wave * (2 * mom_len + WAVE);
     double *mom_l = mom_r + mom_len;
     double *ragscr = mom_l + mom_len;
+    // ... and (fill pass) the series entries of the two zones, kept until the zones' far parts are written
+    ScratchEnt *ser_r = reinterpret_cast<ScratchEnt *>(lds_p + thr_len + nw * (2 * mom_len + WAVE)) + wave * (2 * SER_CAP);
+    ScratchEnt *ser_l = ser_r + SER_CAP;
     for (int idx = lane; idx < 2 * mom_len; idx += WAVE) mom_r[idx] = 0.0;
     __builtin_amdgcn_wave_barrier();
     const int64_t grp = P.g_begin + (int64_t)blockIdx.x * nw + wave;
@@ -1490,10 +1502,11 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
         const int kmom = min((int)P.kmom[iA], P.mom_slots);
         // One zone, first half: header slot, near list (pairs, then quads), guard; the far sites' moments go to `mom`; the
         // ragged end is sized.  What the second half needs comes back through the reference arguments.
-        auto zone_near = [&](int base, int dir, double tnear, double tfar, double *mom, int &zbase_o, int &npp_o, int &nqp_o, int &nfar_o,
-                             int &base_o, double &m1p_o, double &m2p_o, int &nragv_o, int &nrmax_o, bool &rag_o, double &zr_o, int &rr_o) {
+        auto zone_near = [&](int base, int dir, double tnear, double tfar, double *mom, ScratchEnt *ser, int &zbase_o, int &npp_o, int &nqp_o,
+                             int &nfar_o, int &base_o, double &m1p_o, double &m2p_o, int &nragv_o, int &nrmax_o, bool &rag_o, double &zr_o,
+                             int &rr_o, int &nser_o) {
             const int zbase = wpos, nbase = zbase + PREP_HDR;
-            int n_pair = 0, n_pair_pad = 0, n_quad = 0, nfar_tot = 0, pad_ro = 0;
+            int n_pair = 0, n_pair_pad = 0, n_quad = 0, nfar_tot = 0, pad_ro = 0, n_ser = 0;
             bool pair_open = true, seen = false;
             double m1p = 0.0, m2p = 0.0;
             auto close_pairs = [&]() {
@@ -1517,8 +1530,15 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                     const double zn = A * fabs(g - tnear);
                     const double th = thr_of(rraw);
                     const int slot = __double2loint(th) & 0xff;
-                    const bool moml = bulk && slot < kmom && zn >= th && nfar_tot < P_FAR_CAP;
-                    const bool nearl = bulk && !moml;
+                    const bool farx = bulk && zn >= th && nfar_tot + n_ser < P_FAR_CAP;      // alpha max|R| <= P_EPS (NaN threshold: never)
+                    const bool moml = farx && slot < kmom;
+                    // a far site whose row has no moment slot: a series entry, while the zone's buffer has room for the whole pass
+                    // (one that still needs more than 8 orders costs as much there as in the product: it stays near)
+                    const bool serx = farx && slot >= kmom && !(zn - th < SER_DMIN);
+                    const unsigned long long ms_ = __ballot(serx);
+                    const bool ser_ok = kmom > 0 && n_ser + __popcll(ms_) <= P.ser_cap;
+                    const bool serl = ser_ok && serx;
+                    const bool nearl = bulk && !moml && !serl;
                     const bool pairl = nearl && zn < LN2;
                     const unsigned long long mm = __ballot(moml), mp = __ballot(pairl), mq = __ballot(nearl && !pairl);
                     const int nfar = __popcll(mm);
@@ -1546,6 +1566,15 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                             }
                         }
                         nfar_tot += nfar;
+                    }
+                    if (ser_ok && ms_ != 0ull) {
+                        if (FILL && serl) {
+                            // order class by how far past the threshold the site lies: x = P_EPS exp(-(z - th)); order k + 1 matters while d < P_D[k - 2]
+                            const double d = zn - th;
+                            const int cls = !(d < P_D[0]) ? 2 : !(d < P_D[1]) ? 3 : !(d < P_D[3]) ? 5 : 8;
+                            ser[n_ser + rank(ms_)] = ScratchEnt{Ev, rraw * P.rowmul, cls};
+                        }
+                        n_ser += __popcll(ms_);
                     }
                     if (pair_open) {
                         if (FILL && pairl) out[nbase + n_pair + rank(mp)] = ScratchEnt{Ev, rraw * P.rowmul, 0};
@@ -1609,11 +1638,11 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                 }
             }
             zbase_o = zbase; npp_o = n_pair_pad; nqp_o = n_quad_pad; nfar_o = nfar_tot; base_o = base; m1p_o = m1p; m2p_o = m2p;
-            nragv_o = nrag_v; nrmax_o = nrmax; rag_o = rag; zr_o = zr; rr_o = rr;
+            nragv_o = nrag_v; nrmax_o = nrmax; rag_o = rag; zr_o = zr; rr_o = rr; nser_o = n_ser;
         };
         // ... second half: the moments of the occupied slots (slot order), the ragged end's entries, and the header
-        auto zone_far = [&](double *mom, int zbase, int n_pair_pad, int n_quad_pad, int nfar_tot, int base, double m1p, double m2p,
-                            int nrag_v, int nrmax, bool rag, double zr, int rr, int tag) {
+        auto zone_far = [&](double *mom, const ScratchEnt *ser, int n_ser, int zbase, int n_pair_pad, int n_quad_pad, int nfar_tot, int base,
+                            double m1p, double m2p, int nrag_v, int nrmax, bool rag, double zr, int rr) {
             int n_occ = 0;
             if (nfar_tot) {
                 __builtin_amdgcn_wave_barrier();
@@ -1675,6 +1704,23 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                 __builtin_amdgcn_wave_barrier();
                 wpos += PREP_MOM * n_occ;
             }
+            // series entries, sorted by class (highest first) and padded to a multiple of four with neutral entries
+            const int n_ser_pad = (n_ser + 3) & ~3;
+            int ser_w = n_ser_pad;
+            if (n_ser) {
+                if (FILL) {
+                    __builtin_amdgcn_wave_barrier();
+                    const ScratchEnt en = lane < n_ser ? ser[lane] : ScratchEnt{0.0, P.row_of_slot[0] * P.rowmul, 2};
+                    const int cls = lane < n_ser ? en.pad : 0;
+                    const unsigned long long m8 = __ballot(cls == 8), m5 = __ballot(cls == 5), m3 = __ballot(cls == 3), m2 = __ballot(cls == 2);
+                    const int c8 = __popcll(m8), c5 = c8 + __popcll(m5), c3 = c5 + __popcll(m3);
+                    const int dst = cls == 8 ? rank(m8) : cls == 5 ? c8 + rank(m5) : cls == 3 ? c5 + rank(m3) : cls == 2 ? c3 + rank(m2) : lane;
+                    if (lane < n_ser_pad) out[wpos + dst] = en;
+                    ser_w |= c8 << 8 | c5 << 16 | c3 << 24;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                wpos += n_ser_pad;
+            }
             if (rag) {
                 if (FILL) {
                     if (lane < nrmax) out[wpos + lane] = ScratchEnt{exp_neg(zr), rr * P.rowmul, 0};
@@ -1693,20 +1739,20 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                 if (lane == 0) {
                     int4 *o = reinterpret_cast<int4 *>(out + zbase);
                     o[0] = int4{PREP_MAGIC | (rag ? 1 : 0), n_pair_pad, n_quad_pad, n_occ};
-                    o[1] = int4{nfar_tot, rag ? nrmax : 0, rag ? PREP_ZONE_DONE : base, tag};
+                    o[1] = int4{nfar_tot + n_ser, rag ? nrmax : 0, rag ? PREP_ZONE_DONE : base, ser_w};      // n_far: every site of the far field
                     o[2] = int4{w0, w1, w2, w3};
                 }
             }
         };
         // stream order: both zones' near lists, then both zones' far fields (the consumer multiplies first and takes ONE exp
         // per test site for the two far fields together)
-        int zbR, nppR, nqpR, nfR, beR, nrvR, nrmR, rrR, zbL, nppL, nqpL, nfL, beL, nrvL, nrmL, rrL;
+        int zbR, nppR, nqpR, nfR, beR, nrvR, nrmR, rrR, nsR, zbL, nppL, nqpL, nfL, beL, nrvL, nrmL, rrL, nsL;
         bool ragR, ragL;
         double m1R, m2R, zrR, m1L, m2L, zrL;
-        zone_near(R_int, +1, tL, t0, mom_r, zbR, nppR, nqpR, nfR, beR, m1R, m2R, nrvR, nrmR, ragR, zrR, rrR);
-        zone_near(L_int - 1, -1, t0, tL, mom_l, zbL, nppL, nqpL, nfL, beL, m1L, m2L, nrvL, nrmL, ragL, zrL, rrL);
-        zone_far(mom_r, zbR, nppR, nqpR, nfR, beR, m1R, m2R, nrvR, nrmR, ragR, zrR, rrR, iA * 2);
-        zone_far(mom_l, zbL, nppL, nqpL, nfL, beL, m1L, m2L, nrvL, nrmL, ragL, zrL, rrL, iA * 2 + 1);
+        zone_near(R_int, +1, tL, t0, mom_r, ser_r, zbR, nppR, nqpR, nfR, beR, m1R, m2R, nrvR, nrmR, ragR, zrR, rrR, nsR);
+        zone_near(L_int - 1, -1, t0, tL, mom_l, ser_l, zbL, nppL, nqpL, nfL, beL, m1L, m2L, nrvL, nrmL, ragL, zrL, rrL, nsL);
+        zone_far(mom_r, ser_r, nsR, zbR, nppR, nqpR, nfR, beR, m1R, m2R, nrvR, nrmR, ragR, zrR, rrR);
+        zone_far(mom_l, ser_l, nsL, zbL, nppL, nqpL, nfL, beL, m1L, m2L, nrvL, nrmL, ragL, zrL, rrL);
     }
     const int units = (wpos + 3) & ~3;
     if (!FILL) {
@@ -1747,6 +1793,12 @@ struct PrepView {
 
 template <int J, bool USE_LDS>
 __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(ScanParams P, PrepView V) {
+#ifdef BMX_PROFILE
+    // sections: 0 sites between the test sites, 1 zone header, 2 pair list, 3 quad list, 4 generic walks past the zones, 5 fold of the
+    // moments, 6 series entries, 7 ragged end + Horner, 8 exp + apply, 9 renormalise + best-tracking, 10 group set-up, 11 winners out
+    long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev_ = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then per wave: ring + scratch, sites between the test sites
     constexpr int SP = WAVE / J;
     constexpr int BS = J >= 16 ? 4 : 8;
@@ -1859,6 +1911,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
         };
         stage();
         stage();
+        PROF_MARK(10);
 
         double acc[J], bestM[J];
         int E[J], bestK[J];
@@ -1933,8 +1986,9 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
 
             // One zone of the blob, first half: header and near-list products; returns where the generic walk goes on.  What
             // the far half needs later (after BOTH near lists) comes back through the references; fv: lane j holds F_j.
-            auto zone_near = [&](int dir, double tnear, double &fv_o, int &nocc_o, int &nfar_o, int &nrmax_o, bool &rag_o, int &nragv_o) -> int {
-                nocc_o = 0; nfar_o = 0; nrmax_o = 0; rag_o = false; nragv_o = 0;
+            auto zone_near = [&](int dir, double tnear, double &fv_o, int &nocc_o, int &nfar_o, int &nrmax_o, bool &rag_o, int &nragv_o,
+                                 int &nser_o) -> int {
+                nocc_o = 0; nfar_o = 0; nrmax_o = 0; rag_o = false; nragv_o = 0; nser_o = 0;
                 fv_o = 0.0;
                 if (bad) return PREP_ZONE_DONE;
                 double F[J];
@@ -1951,17 +2005,19 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 const int n_pair = __builtin_amdgcn_readfirstlane(h0.y), n_quad = __builtin_amdgcn_readfirstlane(h0.z);
                 const int n_occ = __builtin_amdgcn_readfirstlane(h0.w);
                 const int nfar_tot = __builtin_amdgcn_readfirstlane(h1.x), nrmax = __builtin_amdgcn_readfirstlane(h1.y);
-                const int base_end = __builtin_amdgcn_readfirstlane(h1.z);
+                const int base_end = __builtin_amdgcn_readfirstlane(h1.z), ser_w = __builtin_amdgcn_readfirstlane(h1.w);
+                const int n_ser = ser_w & 0xff, c8 = (ser_w >> 8) & 0xff, c5 = (ser_w >> 16) & 0xff, c3 = (ser_w >> 24) & 0xff;
                 const bool rag = (magic & 1) != 0;
                 if ((magic & ~1) != PREP_MAGIC || n_pair < 0 || n_quad < 0 || n_pair > N + 8 || n_quad > N + 8 || n_occ < 0 || n_occ > MOM_SLOTS ||
-                    nrmax < 0 || nrmax >= WAVE) {
+                    nrmax < 0 || nrmax >= WAVE || n_ser > SER_CAP || (n_ser & 3) || c8 > c5 || c5 > c3 || c3 > n_ser) {
                     bad = true;
                     return PREP_ZONE_DONE;
                 }
                 // n_j of this lane's test site (ragged end)
                 nragv_o = (int)reinterpret_cast<const unsigned char *>(hp + 2)[jl];
-                nocc_o = n_occ; nfar_o = nfar_tot; nrmax_o = nrmax; rag_o = rag;
+                nocc_o = n_occ; nfar_o = nfar_tot; nrmax_o = nrmax; rag_o = rag; nser_o = ser_w;
                 pos += PREP_HDR;
+                PROF_MARK(1);
 
                 if (n_pair > 0) {
                     need();
@@ -2010,6 +2066,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         pos += BS;
                     }
                 }
+                PROF_MARK(2);
                 if (n_quad > 0) {
                     need();
                     int span8q = 0;
@@ -2059,13 +2116,15 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         pos += 4;
                     }
                 }
+                PROF_MARK(3);
                 pos += PREP_GUARD;
                 return base_end;
             };
 
             // ... second half, after both zones' near lists: fold the zone's moments, walk its ragged end, and ADD the log of
             // the factor each test site's product has to pick up to farg (the exp is taken once for both zones)
-            auto zone_far = [&](auto dirc, double fv, int n_occ, int nfar_tot, int nrmax, bool rag, int nrag_v, double (&farg)[J]) {
+            auto zone_far = [&](auto dirc, double fv, int n_occ, int ser_w, int nfar_tot, int nrmax, bool rag, int nrag_v, double (&farg)[J]) {
+                const int n_ser = ser_w & 0xff, ser_cls = ser_w >> 8;        // entries; cumulative class counts (8, 5, 3), 8 bits each
                 constexpr int dir = decltype(dirc)::value;        // compile-time: farg[j] and F[j] below are registers, not indexed memory
                 if (bad || !(nfar_tot || rag)) return;
                 double F[J];
@@ -2097,15 +2156,71 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     if (two) fold(ub.e, reinterpret_cast<const double2 *>(rp + PREP_MOM + 1), Rb2);
                     pos += two ? 2 * PREP_MOM : PREP_MOM;
                 }
+                PROF_MARK(5);
+                // series entries: p_k += (E R)^k up to the order the entry's class needs.  The wave reads them all at once, lanes over
+                // entries; one entry at a time then comes out of the registers (readlane) -- its R is the only load in the loop, four
+                // entries ahead.  The producer sorted them by class, highest first: one branch-free loop per class (a lower-class
+                // entry that rides along in the last batch of a higher class only gets more terms than it needs).
+                if (n_ser > 0) {
+                    need();
+                    const ScratchEnt mine = ring[(pos + lane) & (RING_UNITS - 1)];
+                    const int e8 = (ser_cls & 0x7f) + 3 & ~3, e5 = max(e8, ((ser_cls >> 8) & 0x7f) + 3 & ~3), e3 = max(e5, ((ser_cls >> 16) & 0x7f) + 3 & ~3);
+                    double Rn[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) Rn[u] = loadR(__builtin_amdgcn_readlane(mine.ro, u));
+                    auto batch = [&](auto kc, int s0) {
+                        constexpr int K = decltype(kc)::value;
+                        double Rc[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) Rc[u] = Rn[u];
+                        const int nx = s0 + 4 < n_ser ? s0 + 4 : s0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) Rn[u] = loadR(__builtin_amdgcn_readlane(mine.ro, nx + u));
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const double v = readlane_f64(mine.e, s0 + u) * Rc[u];
+                            pk[0] += v;
+                            if (K == 2) {
+                                pk[1] = fma(v, v, pk[1]);
+                            } else {
+                                const double v2 = v * v;
+                                pk[1] += v2;
+                                pk[2] = fma(v2, v, pk[2]);
+                                if (K > 3) {
+                                    const double v4 = v2 * v2;
+                                    pk[3] += v4;
+                                    pk[4] = fma(v4, v, pk[4]);
+                                    if (K > 5) {
+                                        pk[5] = fma(v4, v2, pk[5]);
+                                        pk[6] = fma(v4 * v2, v, pk[6]);
+                                        pk[7] = fma(v4, v4, pk[7]);
+                                    }
+                                }
+                            }
+                        }
+                    };
+                    int s0 = 0;
+                    for (; s0 < e8; s0 += 4) batch(std::integral_constant<int, 8>{}, s0);
+                    for (; s0 < e5; s0 += 4) batch(std::integral_constant<int, 5>{}, s0);
+                    for (; s0 < e3; s0 += 4) batch(std::integral_constant<int, 3>{}, s0);
+                    for (; s0 < n_ser; s0 += 4) batch(std::integral_constant<int, 2>{}, s0);
+                    pos += n_ser;
+                }
+                PROF_MARK(6);
                 need();
 #pragma unroll
                 for (int k = 0; k < P_ORDER; ++k) pk[k] *= P_W[k];
+                // the ragged end (< 64 entries and a guard): read at once, lanes over entries; the walk below takes an entry out of the
+                // registers and has its R loaded ahead.  (The rotation by moves waits for the newest load, so the distance is one step in
+                // effect; three registers taken in turn under a phase variable measured 5 % slower: r03 notes in DESIGN.md.)
                 int l = 0;
-                double rag_e = 0.0, rag_R = 0.0;
+                ScratchEnt ragm = ScratchEnt{0.0, 0, 0};
+                double rag_R0 = 0.0, rag_R1 = 0.0, rag_R2 = 0.0;
                 if (rag) {
-                    const ScratchEnt en = ring[pos & (RING_UNITS - 1)];
-                    rag_e = en.e;
-                    rag_R = loadR(en.ro);
+                    ragm = ring[(pos + lane) & (RING_UNITS - 1)];
+                    rag_R0 = loadR(__builtin_amdgcn_readlane(ragm.ro, 0));
+                    rag_R1 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(1, nrmax)));
+                    rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(2, nrmax)));
                 }
 #pragma unroll
                 for (int w = 0; w < J; ++w) {
@@ -2113,10 +2228,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     if (rag) {
                         const int nj = __builtin_amdgcn_readlane(nrag_v, j);
                         for (; l < nj; ++l) {
-                            const double v = rag_e * rag_R, v2 = v * v;
-                            const ScratchEnt en = ring[(pos + l + 1) & (RING_UNITS - 1)];     // one step ahead (the guard at the end)
-                            rag_e = en.e;
-                            rag_R = loadR(en.ro);
+                            const double v = readlane_f64(ragm.e, l) * rag_R0, v2 = v * v;
+                            rag_R0 = rag_R1;
+                            rag_R1 = rag_R2;
+                            rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(l + 3, nrmax)));     // (the guard at the end)
                             pk[0] += v;
                             pk[1] = fma(v2, 0.5, pk[1]);
                             pk[2] = fma(v2 * v, 0.3333333333333333, pk[2]);
@@ -2129,9 +2244,11 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     farg[j] = fma(-f, t, farg[j]);              // exp_neg's argument: the factor is exp(f t)
                 }
                 if (rag) pos += nrmax + PREP_RAG_GUARD;
+                PROF_MARK(7);
             };
 
             // sites between / at the test sites (and any part of the windows not covered by bulk)
+            PROF_MARK(9);
             if (BMX_MIDTRI && mid_tri && A * (tL - t0) <= P.zcut) {
                 const double xk = A * (tj - t0);
                 double Gk, Hk;
@@ -2176,14 +2293,17 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
             } else {
                 for (int b = L_int; b < R_int; b += SP) generic_pass(b, +1, R_int, staged);
             }
+            PROF_MARK(0);
             // right side, left side: near lists and whatever the zones do not cover
             double fvR, fvL;
-            int noccR, nfarR, nrmR, nrvR, noccL, nfarL, nrmL, nrvL;
+            int noccR, nfarR, nrmR, nrvR, nserR, noccL, nfarL, nrmL, nrvL, nserL;
             bool ragR, ragL;
-            int b = zone_near(+1, tL, fvR, noccR, nfarR, nrmR, ragR, nrvR);
+            int b = zone_near(+1, tL, fvR, noccR, nfarR, nrmR, ragR, nrvR, nserR);
             if (b != PREP_ZONE_DONE) { while (!generic_pass(b, +1, N, false)) b += SP; }
-            b = zone_near(-1, t0, fvL, noccL, nfarL, nrmL, ragL, nrvL);
+            PROF_MARK(4);
+            b = zone_near(-1, t0, fvL, noccL, nfarL, nrmL, ragL, nrvL, nserL);
             if (b != PREP_ZONE_DONE) { while (!generic_pass(b, -1, -1, false)) b -= SP; }
+            PROF_MARK(4);
             // the far fields of both zones: ONE exp per test site -- test sites in pairs, two interleaved exp chains, each pair
             // final before the next one starts
             if (!bad && (nfarR || ragR || nfarL || ragL)) {
@@ -2201,20 +2321,20 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         farg[w] = 0.0;
                         farg[w + 1] = 0.0;
                     }
+                    PROF_MARK(8);
                 };
                 // exponent budget: a zone's far field moves a product by at most (sites) * far_bits bits (< 860 by P_FAR_CAP); both
                 // zones in one exp only while their sum fits, else one after the other with the exponents pulled out in between
                 const int bitsR = 2 + (int)((float)(nfarR + nrmR) * P.far_bits), bitsL = 2 + (int)((float)(nfarL + nrmL) * P.far_bits);
-                zone_far(std::integral_constant<int, +1>{}, fvR, noccR, nfarR, nrmR, ragR, nrvR, farg);
-                if (bitsR + bitsL > 900) {
+                // (one copy of each zone's code: this kernel's per-A path is about as large as the instruction cache)
+                const bool split = bitsR + bitsL > 900;
+                zone_far(std::integral_constant<int, +1>{}, fvR, noccR, nserR, nfarR, nrmR, ragR, nrvR, farg);
+                if (split) {
                     spend(bitsR);
                     apply_far();
-                    zone_far(std::integral_constant<int, -1>{}, fvL, noccL, nfarL, nrmL, ragL, nrvL, farg);
-                    spend(bitsL);
-                } else {
-                    zone_far(std::integral_constant<int, -1>{}, fvL, noccL, nfarL, nrmL, ragL, nrvL, farg);
-                    spend(bitsR + bitsL);
                 }
+                zone_far(std::integral_constant<int, -1>{}, fvL, noccL, nserL, nfarL, nrmL, ragL, nrvL, farg);
+                spend(split ? bitsL : bitsR + bitsL);
                 apply_far();
             }
 
@@ -2231,6 +2351,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
             }
             if (bad) break;
         }
+        PROF_MARK(9);
         if (bad && lane == 0) atomicOr(V.status, 2);
 #pragma unroll
         for (int j = 0; j < J; ++j) {
@@ -2251,7 +2372,12 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 P.part_ns[o] = bE;
             }
         }
+        PROF_MARK(11);
     }
+#ifdef BMX_PROFILE
+    if (lane == 0 && P.prof)
+        for (int k = 0; k < 12; ++k) atomicAdd(P.prof + k, (unsigned long long)prof_[k]);
+#endif
 }
 
 // ----------------------------------------------------------------------------- K2, prepared, one test site per wave
@@ -2807,6 +2933,7 @@ struct ChromSlot {
     int row_of_slot[MOM_SLOTS] = {0};
     int nslots = 0;              // rows ranked by frequency: row_of_slot[0 .. nslots)
     int kmom_max = 0;            // the most slots any A uses
+    int kmom_max_ser = 0;        // ... in the prepared group kernels' table (second half of kmom)
     // tests
     bool has_tests = false;
     int64_t M = 0;
@@ -3199,10 +3326,13 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
     }
     s->wide_rows = wide;
     {
-        // Moment slots for the grouped kernel's far field: rank the rows by how many sites carry them.
+        // Moment slots for the far field: rank the rows by how many sites carry them.
         // Slot s pays at a given A when the ~23 instructions saved per far site of that row outweigh
         // the ~30 instructions its term costs at the end of each zone; the expected number of far sites
         // per zone follows from the mean site density (a performance heuristic only: any choice is exact).
+        // The prepared group kernels have a cheaper place than the product for a far site without a slot
+        // (series entries, ~11 instructions less than the product): a second table with that gain for them
+        // (measured optimum 10-12, flat: profiles/r03_series_entries.txt).
         std::vector<int> order((size_t)c->rows);
         for (int r = 0; r < c->rows; r++) order[(size_t)r] = r;
         const size_t ns = std::min((size_t)MOM_SLOTS, order.size());
@@ -3220,16 +3350,19 @@ int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t
         s->nslots = nslots;
         const int kcap = diag_env("BMX_MOM_SLOTS") ? std::min(std::max(atoi(diag_env("BMX_MOM_SLOTS")), 0), MOM_SLOTS) : MOM_SLOTS;
         const double range = genpos[N - 1] - genpos[0];
-        std::vector<uint8_t> km((size_t)c->nA, 0);
-        for (int a = 0; a < c->nA; a++) {
-            const double nfar = range > 0 ? 0.8 * (double)(N - 1) / range * c->zcut / c->h_A[(size_t)a] : (double)N;
-            int k = 0;
-            const double gain = diag_env("BMX_KMOM_GAIN") ? atof(diag_env("BMX_KMOM_GAIN")) : 23.0;      // threshold experiments
-            while (k < nslots && k < kcap && (double)cnt[(size_t)s->row_of_slot[k]] / (double)N * nfar * gain > 30.0) k++;
-            km[(size_t)a] = (uint8_t)k;
-        }
+        std::vector<uint8_t> km(2 * (size_t)c->nA, 0);            // [0, nA): solo / round-2 kernels; [nA, 2 nA): prepared group kernels
         s->kmom_max = 0;
-        for (int a = 0; a < c->nA; a++) s->kmom_max = std::max(s->kmom_max, (int)km[(size_t)a]);
+        s->kmom_max_ser = 0;
+        for (int t = 0; t < 2; t++) {
+            const double gain = diag_env("BMX_KMOM_GAIN") ? atof(diag_env("BMX_KMOM_GAIN")) : t ? 11.0 : 23.0;      // (threshold experiments)
+            for (int a = 0; a < c->nA; a++) {
+                const double nfar = range > 0 ? 0.8 * (double)(N - 1) / range * c->zcut / c->h_A[(size_t)a] : (double)N;
+                int k = 0;
+                while (k < nslots && k < kcap && (double)cnt[(size_t)s->row_of_slot[k]] / (double)N * nfar * gain > 30.0) k++;
+                km[(size_t)t * c->nA + a] = (uint8_t)k;
+                (t ? s->kmom_max_ser : s->kmom_max) = std::max(t ? s->kmom_max_ser : s->kmom_max, k);
+            }
+        }
         // the kernel reads max |R| and the slot of a row with one load: the slot sits in the low mantissa
         // byte of the (rounded up) maximum; +inf becomes NaN, which never compares as far
         std::vector<double> packed(c->h_rowmax.size());
@@ -3462,13 +3595,13 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
         pl.thr_in_lds = c->rows <= PREP_THR_LDS_MAX ? 1 : 0;
         // the moment slots of prep_kernel: 64 with the table in LDS, all of them otherwise (see above) -- but no more than any A
         // uses: the moment arrays are most of that kernel's LDS, and LDS per wave decides how many of its waves a CU holds
-        const int pm = std::max(1, std::min(use_lds ? MOM_SLOTS_LDS : MOM_SLOTS, s->kmom_max));
+        const int pm = std::max(1, std::min(use_lds ? MOM_SLOTS_LDS : MOM_SLOTS, (prepared && J == 16) ? s->kmom_max_ser : s->kmom_max));
         P.mom_slots = pm;
         const size_t mom_fill = solo ? (size_t)(pm + S_COPIES - 1 + 3) * S_ORDER : 2 * (size_t)(pm + P_COPIES - 1 + 3) * P_ORDER + WAVE;
         const size_t mom_count = solo ? mom_fill : 2 * (size_t)(pm + P_COPIES - 1 + 3) + WAVE;      // grouped counting pass: one flag per slot
         pl.prep_threads = mom_fill * sizeof(double) > 20480 ? PREP_THREADS / 4 : PREP_THREADS;          // (all 254 slots: 25 KB per moment array)
         const size_t thr_b = pl.thr_in_lds ? (size_t)((c->rows + 1) & ~1) * sizeof(double) : 0;
-        pl.prep_lds = thr_b + (size_t)(pl.prep_threads / WAVE) * mom_fill * sizeof(double);
+        pl.prep_lds = thr_b + (size_t)(pl.prep_threads / WAVE) * (mom_fill * sizeof(double) + (solo ? 0 : 2 * SER_CAP * sizeof(ScratchEnt)));
         pl.prep_lds_count = thr_b + (size_t)(pl.prep_threads / WAVE) * mom_count * sizeof(double);
         P.far_bits = (float)(P_EPS * 1.4427 * 1.1);          // |log1p(x)| <= 1.09 |x| for |x| <= 0.15 (1.16 at 0.25: order 16 uses 1.2)
         if (P_ORDER == 16) P.far_bits = (float)(P_EPS * 1.4427 * 1.2);
@@ -3498,7 +3631,10 @@ PrepParams prep_params(bmx_ctx *c, ChromSlot *s, const ScanPlan &pl) {
     Q.test_gen = s->test_gen.p; Q.win_lo = s->win_lo.p; Q.win_hi = s->win_hi.p; Q.center = s->center.p; Q.center_hi = s->center_hi.p;
     Q.M = s->M; Q.zcut = c->zcut;
     Q.rowthr = s->rowthr.p; Q.thr_in_lds = pl.thr_in_lds;
-    Q.kmom = s->kmom.p; Q.row_of_slot = s->d_row_of_slot.p; Q.mom_slots = pl.P.mom_slots;
+    // series entries only where they are cheaper than the product: groups of 16 (a product entry costs 1.5 instructions per test site)
+    const bool series = pl.mode == 4 && pl.J == 16;
+    Q.kmom = s->kmom.p + (series ? c->nA : 0); Q.row_of_slot = s->d_row_of_slot.p; Q.mom_slots = pl.P.mom_slots;
+    Q.ser_cap = !series ? 0 : diag_env("BMX_SER_CAP") ? std::min(std::max(atoi(diag_env("BMX_SER_CAP")), 0), SER_CAP) : SER_CAP;
     Q.g_begin = 0; Q.g_end = 0;
     Q.blob_units = s->blob_units.p; Q.blob_prefix = s->blob_prefix.p; Q.prefix_base = 0;
     Q.arena = c->arena.p; Q.status = c->d_status;
@@ -3687,7 +3823,10 @@ int bmx_ctx_sync(bmx_ctx *c) {
         static const char *nm[12] = {"between test sites", "zone set-up", "per-pass: rank, list position, tail", "near-list block loops", "ragged-end masks",
                                     "fold of moments", "flush", "generic walks past zones", "best-tracking", "near-list set-up",
                                     "per-pass: loads, exp, classify", "per-pass: moment adds"};
-        if (tot > 0) for (int k = 0; k < 12; k++) fprintf(stderr, "[bmx prof] %-36s %5.1f %%\n", nm[k], 100.0 * (double)h[k] / tot);
+        static const char *np[12] = {"between test sites", "zone header", "pair lists", "quad lists", "generic walks past zones", "fold of moments",
+                                    "series entries", "ragged end + Horner", "exp + apply", "renormalise + best-tracking", "group set-up", "winners out"};
+        const bool prep_names = diag_env("BMX_PROF_PREPARED") != nullptr;
+        if (tot > 0) for (int k = 0; k < 12; k++) fprintf(stderr, "[bmx prof] %-36s %5.1f %%\n", (prep_names ? np : nm)[k], 100.0 * (double)h[k] / tot);
     }
 #endif
     return check_status(c);
