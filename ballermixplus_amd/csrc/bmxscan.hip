@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
         // One zone, first half: header slot, near list (pairs, then quads), guard; the far sites' moments go to `mom`; the
         // ragged end is sized.  What the second half needs comes back through the reference arguments.
         auto zone_near = [&](int base, int dir, double tnear, double tfar, double *mom, ScratchEnt *ser, int &zbase_o, int &npp_o, int &nqp_o,
-                             int &nfar_o, int &base_o, double &m1p_o, double &m2p_o, int &nragv_o, int &nrmax_o, bool &rag_o, double &zr_o,
+                             int &nfar_o, int &base_o, double &m1p_o, double &m2p_o, int &nragv_o, int &nrmax_o, int &rag_o, double &zr_o,
                              int &rr_o, int &nser_o) {
             const int zbase = wpos, nbase = zbase + PREP_HDR;
             int n_pair = 0, n_pair_pad = 0, n_quad = 0, nfar_tot = 0, pad_ro = 0, n_ser = 0;
@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                     // (one that still needs more than 8 orders costs as much there as in the product: it stays near)
                     const bool serx = farx && slot >= kmom && !(zn - th < SER_DMIN);
                     const unsigned long long ms_ = __ballot(serx);
-                    const bool ser_ok = kmom > 0 && n_ser + __popcll(ms_) <= P.ser_cap;
+                    const bool ser_ok = n_ser + __popcll(ms_) <= P.ser_cap;
                     const bool serl = ser_ok && serx;
                     const bool nearl = bulk && !moml && !serl;
                     const bool pairl = nearl && zn < LN2;
@@ -1600,10 +1600,10 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
 
             // ragged far end (see the grouped kernel): per-window counts n_j by bisection with the scan's own predicate
             int nrag_v = 0, nrmax = 0;
-            bool rag = false;
+            int rag = 0;                 // bit 0: the ragged end goes into the stream; bit 1: some of its sites need more than three orders
             double zr = 0.0;
             int rr = 0;
-            if (kmom) {
+            {   // (also where no row has a moment slot: series entries and the ragged end do not need one)
                 const int ir = base + dir * lane;
                 const bool inr = ir >= 0 && ir < N;
                 const int ic = min(max(ir, 0), N - 1);
@@ -1633,8 +1633,11 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                 }
                 if (okr && nrmax > 0 && nrmax < WAVE) {
                     zr = A * fabs(g - tnear);
-                    const bool far3 = lane >= nrmax || zr >= thr_of(rr) + P_RAG_D;      // alpha max|R| <= 3e-4; NaN (absent row): false
-                    rag = __ballot(far3) == ~0ull;
+                    // every site of it far enough for eight orders (alpha max|R| <= 0.03; NaN threshold, absent row: false); most of
+                    // the time for three (<= 3e-4).  Anything nearer: the zone ends before it and the scan kernel walks it.
+                    const bool far8 = lane >= nrmax || zr >= thr_of(rr) + SER_DMIN;
+                    const bool far3 = lane >= nrmax || zr >= thr_of(rr) + P_RAG_D;
+                    rag = __ballot(far8) == ~0ull ? (__ballot(far3) == ~0ull ? 1 : 3) : 0;
                 }
             }
             zbase_o = zbase; npp_o = n_pair_pad; nqp_o = n_quad_pad; nfar_o = nfar_tot; base_o = base; m1p_o = m1p; m2p_o = m2p;
@@ -1642,7 +1645,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
         };
         // ... second half: the moments of the occupied slots (slot order), the ragged end's entries, and the header
         auto zone_far = [&](double *mom, const ScratchEnt *ser, int n_ser, int zbase, int n_pair_pad, int n_quad_pad, int nfar_tot, int base,
-                            double m1p, double m2p, int nrag_v, int nrmax, bool rag, double zr, int rr) {
+                            double m1p, double m2p, int nrag_v, int nrmax, int rag, double zr, int rr) {
             int n_occ = 0;
             if (nfar_tot) {
                 __builtin_amdgcn_wave_barrier();
@@ -1723,7 +1726,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
             }
             if (rag) {
                 if (FILL) {
-                    if (lane < nrmax) out[wpos + lane] = ScratchEnt{exp_neg(zr), rr * P.rowmul, 0};
+                    if (lane < nrmax) out[wpos + lane] = ScratchEnt{exp_neg(zr), rr * P.rowmul, zr >= thr_of(rr) + P_RAG_D ? 0 : 1};      // 1: orders 4..8 too
                     if (lane == nrmax) out[wpos + lane] = ScratchEnt{0.0, rr * P.rowmul, 0};
                 }
                 wpos += nrmax + PREP_RAG_GUARD;
@@ -1738,7 +1741,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                           w2 = __builtin_amdgcn_readlane(w, 8 % J), w3 = __builtin_amdgcn_readlane(w, 12 % J);
                 if (lane == 0) {
                     int4 *o = reinterpret_cast<int4 *>(out + zbase);
-                    o[0] = int4{PREP_MAGIC | (rag ? 1 : 0), n_pair_pad, n_quad_pad, n_occ};
+                    o[0] = int4{PREP_MAGIC | rag, n_pair_pad, n_quad_pad, n_occ};
                     o[1] = int4{nfar_tot + n_ser, rag ? nrmax : 0, rag ? PREP_ZONE_DONE : base, ser_w};      // n_far: every site of the far field
                     o[2] = int4{w0, w1, w2, w3};
                 }
@@ -1747,7 +1750,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
         // stream order: both zones' near lists, then both zones' far fields (the consumer multiplies first and takes ONE exp
         // per test site for the two far fields together)
         int zbR, nppR, nqpR, nfR, beR, nrvR, nrmR, rrR, nsR, zbL, nppL, nqpL, nfL, beL, nrvL, nrmL, rrL, nsL;
-        bool ragR, ragL;
+        int ragR, ragL;
         double m1R, m2R, zrR, m1L, m2L, zrL;
         zone_near(R_int, +1, tL, t0, mom_r, ser_r, zbR, nppR, nqpR, nfR, beR, m1R, m2R, nrvR, nrmR, ragR, zrR, rrR, nsR);
         zone_near(L_int - 1, -1, t0, tL, mom_l, ser_l, zbL, nppL, nqpL, nfL, beL, m1L, m2L, nrvL, nrmL, ragL, zrL, rrL, nsL);
@@ -1986,9 +1989,9 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
 
             // One zone of the blob, first half: header and near-list products; returns where the generic walk goes on.  What
             // the far half needs later (after BOTH near lists) comes back through the references; fv: lane j holds F_j.
-            auto zone_near = [&](int dir, double tnear, double &fv_o, int &nocc_o, int &nfar_o, int &nrmax_o, bool &rag_o, int &nragv_o,
+            auto zone_near = [&](int dir, double tnear, double &fv_o, int &nocc_o, int &nfar_o, int &nrmax_o, int &rag_o, int &nragv_o,
                                  int &nser_o) -> int {
-                nocc_o = 0; nfar_o = 0; nrmax_o = 0; rag_o = false; nragv_o = 0; nser_o = 0;
+                nocc_o = 0; nfar_o = 0; nrmax_o = 0; rag_o = 0; nragv_o = 0; nser_o = 0;
                 fv_o = 0.0;
                 if (bad) return PREP_ZONE_DONE;
                 double F[J];
@@ -2007,8 +2010,8 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 const int nfar_tot = __builtin_amdgcn_readfirstlane(h1.x), nrmax = __builtin_amdgcn_readfirstlane(h1.y);
                 const int base_end = __builtin_amdgcn_readfirstlane(h1.z), ser_w = __builtin_amdgcn_readfirstlane(h1.w);
                 const int n_ser = ser_w & 0xff, c8 = (ser_w >> 8) & 0xff, c5 = (ser_w >> 16) & 0xff, c3 = (ser_w >> 24) & 0xff;
-                const bool rag = (magic & 1) != 0;
-                if ((magic & ~1) != PREP_MAGIC || n_pair < 0 || n_quad < 0 || n_pair > N + 8 || n_quad > N + 8 || n_occ < 0 || n_occ > MOM_SLOTS ||
+                const int rag = magic & 3;
+                if ((magic & ~3) != PREP_MAGIC || rag == 2 || n_pair < 0 || n_quad < 0 || n_pair > N + 8 || n_quad > N + 8 || n_occ < 0 || n_occ > MOM_SLOTS ||
                     nrmax < 0 || nrmax >= WAVE || n_ser > SER_CAP || (n_ser & 3) || c8 > c5 || c5 > c3 || c3 > n_ser) {
                     bad = true;
                     return PREP_ZONE_DONE;
@@ -2123,7 +2126,8 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
 
             // ... second half, after both zones' near lists: fold the zone's moments, walk its ragged end, and ADD the log of
             // the factor each test site's product has to pick up to farg (the exp is taken once for both zones)
-            auto zone_far = [&](auto dirc, double fv, int n_occ, int ser_w, int nfar_tot, int nrmax, bool rag, int nrag_v, double (&farg)[J]) {
+            auto zone_far = [&](auto dirc, double fv, int n_occ, int ser_w, int nfar_tot, int nrmax, int ragf, int nrag_v, double (&farg)[J]) {
+                const bool rag = (ragf & 1) != 0, rag_hi = (ragf & 2) != 0;
                 const int n_ser = ser_w & 0xff, ser_cls = ser_w >> 8;        // entries; cumulative class counts (8, 5, 3), 8 bits each
                 constexpr int dir = decltype(dirc)::value;        // compile-time: farg[j] and F[j] below are registers, not indexed memory
                 if (bad || !(nfar_tot || rag)) return;
@@ -2146,15 +2150,40 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         pk[k - 1] = fma((k & 1) ? v.y : v.x, pw[k], pk[k - 1]);
                     }
                 };
-                for (int s = 0; s < n_occ; s += 2) {
+                // two slots per step.  With the table in L2 / HBM the heads (M_1, row) and the R of the NEXT two are requested before this
+                // step's powers (+3.4 / +4.2 % at 11 / 41 sample sizes); with the table in LDS the extra live values cost more than the
+                // short latency (-0.7 %), so that form asks for its R where it needs it
+                if (!USE_LDS && n_occ > 0) {
                     need();
-                    const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
-                    const bool two = s + 1 < n_occ;
-                    const ScratchEnt ua = rp[0], ub = rp[two ? PREP_MOM : 0];
-                    const double Ra = loadR(ua.ro), Rb2 = loadR(ub.ro);
-                    fold(ua.e, reinterpret_cast<const double2 *>(rp + 1), Ra);
-                    if (two) fold(ub.e, reinterpret_cast<const double2 *>(rp + PREP_MOM + 1), Rb2);
-                    pos += two ? 2 * PREP_MOM : PREP_MOM;
+                    const ScratchEnt *rp0 = ring + (pos & (RING_UNITS - 1));
+                    ScratchEnt ua = rp0[0], ub = rp0[n_occ > 1 ? PREP_MOM : 0];
+                    double Ra = loadR(ua.ro), Rb2 = loadR(ub.ro);
+                    for (int s = 0; s < n_occ; s += 2) {
+                        need();
+                        const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
+                        const bool two = s + 1 < n_occ;
+                        const double m1a = ua.e, m1b = ub.e, Rca = Ra, Rcb = Rb2;
+                        const int na = s + 2 < n_occ ? 2 * PREP_MOM : 0, nb = s + 3 < n_occ ? 3 * PREP_MOM : na;     // (the last step: itself again)
+                        ua = rp[na];
+                        ub = rp[nb];
+                        Ra = loadR(ua.ro);
+                        Rb2 = loadR(ub.ro);
+                        fold(m1a, reinterpret_cast<const double2 *>(rp + 1), Rca);
+                        if (two) fold(m1b, reinterpret_cast<const double2 *>(rp + PREP_MOM + 1), Rcb);
+                        pos += two ? 2 * PREP_MOM : PREP_MOM;
+                    }
+                }
+                if (USE_LDS) {
+                    for (int s = 0; s < n_occ; s += 2) {
+                        need();
+                        const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
+                        const bool two = s + 1 < n_occ;
+                        const ScratchEnt ua = rp[0], ub = rp[two ? PREP_MOM : 0];
+                        const double Ra = loadR(ua.ro), Rb2 = loadR(ub.ro);
+                        fold(ua.e, reinterpret_cast<const double2 *>(rp + 1), Ra);
+                        if (two) fold(ub.e, reinterpret_cast<const double2 *>(rp + PREP_MOM + 1), Rb2);
+                        pos += two ? 2 * PREP_MOM : PREP_MOM;
+                    }
                 }
                 PROF_MARK(5);
                 // series entries: p_k += (E R)^k up to the order the entry's class needs.  The wave reads them all at once, lanes over
@@ -2243,6 +2272,24 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     for (int k = P_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
                     farg[j] = fma(-f, t, farg[j]);              // exp_neg's argument: the factor is exp(f t)
                 }
+                // (rare) sites of the ragged end with alpha max|R| between 3e-4 and 0.03, flagged by the producer: orders 4 to 8 of each, for
+                // the test sites whose windows hold it -- apart from the walk above, which stays what it was
+                if (rag_hi) {
+                    for (int lh = 0; lh < nrmax; ++lh) {
+                        if (__builtin_amdgcn_readlane(ragm.pad, lh) == 0) continue;
+                        const double v = readlane_f64(ragm.e, lh) * loadR(__builtin_amdgcn_readlane(ragm.ro, lh));
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            const double u = (lh < __builtin_amdgcn_readlane(nrag_v, j)) ? F[j] * v : 0.0;
+                            const double u2 = u * u;
+                            double t = fma(-u, P_W[7], P_W[6]);
+                            t = fma(-u, t, P_W[5]);
+                            t = fma(-u, t, P_W[4]);
+                            t = fma(-u, t, P_W[3]);
+                            farg[j] = fma(u2 * u2, t, farg[j]);
+                        }
+                    }
+                }
                 if (rag) pos += nrmax + PREP_RAG_GUARD;
                 PROF_MARK(7);
             };
@@ -2297,7 +2344,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
             // right side, left side: near lists and whatever the zones do not cover
             double fvR, fvL;
             int noccR, nfarR, nrmR, nrvR, nserR, noccL, nfarL, nrmL, nrvL, nserL;
-            bool ragR, ragL;
+            int ragR, ragL;
             int b = zone_near(+1, tL, fvR, noccR, nfarR, nrmR, ragR, nrvR, nserR);
             if (b != PREP_ZONE_DONE) { while (!generic_pass(b, +1, N, false)) b += SP; }
             PROF_MARK(4);

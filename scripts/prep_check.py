@@ -15,13 +15,23 @@ ap.add_argument('--config', type=int, default=3)
 ap.add_argument('--step', type=int, default=1)
 ap.add_argument('--variants', default='12,0,2')
 ap.add_argument('--reps', type=int, default=2)
+ap.add_argument('--n-spread', type=int, default=0, help='sample sizes n - spread .. n drawn per site (bench.py --n-spread)')
 a = ap.parse_args()
 N, n = a.snps, (200 if a.config == 5 else 100)
 phys, gen, k, nn = synth.synth_chromosome(N, n, 1)
+sizes, props = [n], {n: 1.0}
+if a.n_spread > 0:      # as bench.py: n_i uniform in [n - spread, n], counts rescaled
+    rng = np.random.default_rng(77)
+    n2 = rng.integers(n - a.n_spread, n + 1, N)
+    k = np.where(k == nn, n2, np.maximum(1, np.minimum(n2 - 1, (k * n2) // nn)))
+    nn = n2
 spect = {(x, y): f for x, y, f in synth.spect_from_counts(k, nn)}
+if a.n_spread > 0:
+    sizes = sorted(set(nn.tolist()))
+    props = {int(s_): float(sum(f for (x, y), f in spect.items() if y == s_)) for s_ in sizes}
 grid = Grids(None, None, True, True, '100,10000,100', None) if a.config == 5 else Grids(None, None, False, False, None, None)
 xs, ab, As = grid.scan_order()
-model = eng.ModelArrays('B2', int(k.min()), [n], spect, {n: 1.0}, xs, ab)
+model = eng.ModelArrays('B2', int(k.min()), sizes, spect, props, xs, ab)
 ctx = eng.Context(0)
 ctx.set_model(model, As)
 ctx.set_sites(gen, model.rows_of(k, nn))
