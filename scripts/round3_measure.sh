@@ -21,9 +21,10 @@ else
   bash scripts/pmc_collect.sh c5 --config 5 > $O/pmc_c5.log 2>&1
   PMC_KEY=config3_step64 bash scripts/pmc_collect.sh c3s64 --config 3 --snps 4000000 --step 64 > $O/pmc_c3s64.log 2>&1
   PMC_KEY=config3_nspread40 bash scripts/pmc_collect.sh c3ns40 --config 3 --n-spread 40 > $O/pmc_c3ns40.log 2>&1
+  PMC_KEY=config3_nspread10 bash scripts/pmc_collect.sh c3ns10 --config 3 --n-spread 10 > $O/pmc_c3ns10.log 2>&1
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/stats_bench.json 2> $O/stats_bench.err
   cd $R
   find $O/stats -name "*kernel_stats.csv" | xargs cat | cut -c1-220 | head -12
-  for t in c3 c4 c5 c3s64 c3ns40; do head -1 $O/$t/summary.txt | cut -c1-300; grep -E "valu_per_64|cycles_per_valu|hbm_read|hbm_write|l2_hit" $O/$t/summary.txt; done
+  for t in c3 c4 c5 c3s64 c3ns40 c3ns10; do head -1 $O/$t/summary.txt | cut -c1-300; grep -E "valu_per_64|cycles_per_valu|hbm_read|hbm_write|l2_hit" $O/$t/summary.txt; done
 fi
