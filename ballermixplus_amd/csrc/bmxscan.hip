@@ -2251,34 +2251,59 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     rag_R1 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(1, nrmax)));
                     rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(2, nrmax)));
                 }
-                // the zone's common far field: one Horner chain per test site, all sixteen in one straight line (nothing between them:
-                // the scheduler interleaves the chains)
-#pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    const double f = F[j];
-                    double t = pk[P_ORDER - 1];
-#pragma unroll
-                    for (int k = P_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
-                    farg[j] = fma(-f, t, farg[j]);              // exp_neg's argument: the factor is exp(f t)
-                }
-                // ... and the ragged end on top, in sums of its own: walked once, cut at n_j for test site j
-                if (rag) {
-                    double r1 = 0.0, r2 = 0.0, r3 = 0.0;
+                if (USE_LDS) {
+                    // test site by test site: its share of the ragged end into the power sums, then its Horner chain
 #pragma unroll
                     for (int w = 0; w < J; ++w) {
                         const int j = dir > 0 ? w : J - 1 - w;
-                        const int nj = __builtin_amdgcn_readlane(nrag_v, j);
-                        for (; l < nj; ++l) {
-                            const double v = readlane_f64(ragm.e, l) * rag_R0, v2 = v * v;
-                            rag_R0 = rag_R1;
-                            rag_R1 = rag_R2;
-                            rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(l + 3, nrmax)));     // (the guard at the end)
-                            r1 += v;
-                            r2 = fma(v2, 0.5, r2);
-                            r3 = fma(v2 * v, 0.3333333333333333, r3);
+                        if (rag) {
+                            const int nj = __builtin_amdgcn_readlane(nrag_v, j);
+                            for (; l < nj; ++l) {
+                                const double v = readlane_f64(ragm.e, l) * rag_R0, v2 = v * v;
+                                rag_R0 = rag_R1;
+                                rag_R1 = rag_R2;
+                                rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(l + 3, nrmax)));     // (the guard at the end)
+                                pk[0] += v;
+                                pk[1] = fma(v2, 0.5, pk[1]);
+                                pk[2] = fma(v2 * v, 0.3333333333333333, pk[2]);
+                            }
                         }
                         const double f = F[j];
-                        farg[j] = fma(-f, fma(-f, fma(-f, r3, r2), r1), farg[j]);
+                        double t = pk[P_ORDER - 1];
+#pragma unroll
+                        for (int k = P_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
+                        farg[j] = fma(-f, t, farg[j]);              // exp_neg's argument: the factor is exp(f t)
+                    }
+                } else {
+                    // the table in L2 / HBM: the sixteen Horner chains of the zone's common far field in one straight line, then the ragged
+                    // end in sums of its own, walked once and cut at n_j for test site j (0.6 % more instructions, 8 fewer spills: +2.7 %
+                    // here, -0.6 % with the table in LDS, which therefore keeps the form above)
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        const double f = F[j];
+                        double t = pk[P_ORDER - 1];
+#pragma unroll
+                        for (int k = P_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
+                        farg[j] = fma(-f, t, farg[j]);
+                    }
+                    if (rag) {
+                        double r1 = 0.0, r2 = 0.0, r3 = 0.0;
+#pragma unroll
+                        for (int w = 0; w < J; ++w) {
+                            const int j = dir > 0 ? w : J - 1 - w;
+                            const int nj = __builtin_amdgcn_readlane(nrag_v, j);
+                            for (; l < nj; ++l) {
+                                const double v = readlane_f64(ragm.e, l) * rag_R0, v2 = v * v;
+                                rag_R0 = rag_R1;
+                                rag_R1 = rag_R2;
+                                rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(l + 3, nrmax)));     // (the guard at the end)
+                                r1 += v;
+                                r2 = fma(v2, 0.5, r2);
+                                r3 = fma(v2 * v, 0.3333333333333333, r3);
+                            }
+                            const double f = F[j];
+                            farg[j] = fma(-f, fma(-f, fma(-f, r3, r2), r1), farg[j]);
+                        }
                     }
                 }
                 // (rare) sites of the ragged end with alpha max|R| between 3e-4 and 0.03, flagged by the producer: orders 4 to 8 of each, for
