@@ -57,6 +57,8 @@ wall = time.time() - t0
 if r.returncode != 0:
     print(r.stdout[-2000:], r.stderr[-3000:])
     raise SystemExit(r.returncode)
+if os.environ.get('BMX_TRACE'):          # the CLI's own time stamps (stderr), one per file
+    print(r.stderr[-4000:])
 m = re.search(r'selection table built (\d+) time\(s\), scan kernels ([0-9.]+) s', r.stdout)
 kern = float(m.group(2)) if m else float('nan')
 W = sum(sizes)
