@@ -547,7 +547,10 @@ def _run(args):
             if args.n_spread:
                 res['cpu_baseline'] = {'skipped': 'not defined for --n-spread runs (the recipe of the thinned sample sizes is not shared with the workers)'}
             else:
-                res['cpu_baseline'] = cpu_baseline(specs, sizes_c, args.cpu_seconds)
+                try:
+                    res['cpu_baseline'] = cpu_baseline(specs, sizes_c, args.cpu_seconds)
+                except Exception as e:       # the GPU measurement above stands on its own: say what went wrong with the baseline leg
+                    res['cpu_baseline'] = {'error': repr(e)[:500]}
         line = json.dumps(res)
     else:
         line = None
