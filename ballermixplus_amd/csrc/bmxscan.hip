@@ -3627,7 +3627,9 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
     const bool fits = lds_need(mom_slots) <= (size_t)LDS_LIMIT_BYTES && !diag_env("BMX_NO_LDS");   // BMX_NO_LDS: R from L2 (A/B runs)
     if (!fits || c->variant == 1) mom_slots = MOM_SLOTS;
     P.mom_slots = mom_slots;
-    int spb = J ? (s->M >= 65536 ? 64 : 4 * J) : (s->M >= 65536 ? 32 : SITE_THREADS / WAVE);   // per-site kernel: >= one test site per wave
+    // test sites per workgroup: every workgroup loads its R slice into LDS first (52 KB at n = 100, 103 KB at n = 200), so large scans
+    // give each wave two groups of 16 (128 test sites per 4 waves: +0.6 % at config 3, +2 % at config 5 over 64; 256 gains nothing more)
+    int spb = J ? (s->M >= 65536 ? 128 : 4 * J) : (s->M >= 65536 ? 32 : SITE_THREADS / WAVE);   // per-site kernel: >= one test site per wave
     if (J == 16 && spb < 64) spb = 64;
     if (J && diag_env("BMX_SPB")) spb = std::max(4 * J, atoi(diag_env("BMX_SPB")) / (4 * J) * (4 * J));   // experiments
     const bool use_lds = fits && c->variant != 1;
