@@ -73,6 +73,7 @@ PROTOTYPES = {
     'bmx_ctx_slot_count': (C.c_int, [_vp]),
     'bmx_ctx_pack_records': (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _lp]),
     'bmx_ctx_plan': (C.c_int, [_vp, _ip, _ip, _ip, _lp]),
+    'bmx_ctx_launch_ranges': (C.c_int, [_vp, _lp, C.c_int32, _ip]),
     'bmx_ctx_surface': (C.c_int, [_vp, C.c_double, C.c_int64, C.c_int64, _dp, _ip]),
     'bmx_input_count': (C.c_int, [C.c_char_p, _lp]),
     'bmx_input_parse': (C.c_int, [C.c_char_p, C.c_int64, C.c_int, _lp, _dp, _lp, _lp]),

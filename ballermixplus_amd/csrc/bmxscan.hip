@@ -2922,6 +2922,13 @@ void dfree(T *&p) {
 
 }  // namespace
 
+// -DBMX_DEVICE_PROBE=<kernel instantiation>: device code of that ONE kernel and nothing else (register / spill counts and the
+// assembly of a kernel under work in seconds instead of a minute; `make probe K='clr_scan_prepared_kernel<16, true>'`)
+#ifdef BMX_DEVICE_PROBE
+namespace {
+template __global__ void BMX_DEVICE_PROBE(ScanParams, PrepView);
+}
+#else
 
 // bmx_io.cpp: rows [0, n) formatted into `out` (<= 512 bytes per row); grid indices either as (ix, ia, iA) or as the
 // linear index lin = (iA*nx + ix)*nab + ia (< 0: the reference's all-zero row).  Returns the bytes written, 0 on a bad index.
@@ -3885,6 +3892,19 @@ int bmx_ctx_plan(bmx_ctx *c, int32_t *J, int32_t *use_lds, int32_t *mode, int64_
     return BMX_OK;
 }
 
+int bmx_ctx_launch_ranges(bmx_ctx *c, int64_t *offs, int32_t cap, int32_t *n_out) {
+    if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
+    ChromSlot *s = c->cur;
+    if (!c->has_model || !s->has_sites || !s->has_tests) return fail(BMX_E_STATE, "model, sites and tests must be set before the plan exists");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<PrepRange> rs;
+    int rc = scan_ranges(c, s, rs);
+    if (rc) return rc;
+    if (n_out) *n_out = (int32_t)rs.size();
+    for (size_t i = 0; i < rs.size() && (int64_t)i < cap && offs; i++) offs[i] = rs[i].off;
+    return BMX_OK;
+}
+
 int bmx_ctx_sync(bmx_ctx *c) {
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
@@ -4286,3 +4306,5 @@ int bmx_scan_multi(const bmx_model *m, const double *A, int32_t nA, int64_t N, c
 }
 
 }  // extern "C"
+
+#endif  // BMX_DEVICE_PROBE

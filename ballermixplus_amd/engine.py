@@ -98,6 +98,8 @@ class Context:
     def set_sites(self, genpos, rows):
         g, r = _lib.f64(genpos), _lib.i32(rows)
         self.N = len(g)
+        self.M = 0                       # the library drops the slot's test sites (they were located in the old array)
+        self._slot_M.pop(self.slot, None)
         _lib.check(self._L.bmx_ctx_set_sites(self._h, len(g), _lib.as_dp(g), _lib.as_ip(r)))
 
     def set_tests(self, test_gen, win_lo, win_hi):
@@ -131,6 +133,14 @@ class Context:
         else:
             name = 'clr_scan_kernel<%s>' % lds
         return {'J': J.value, 'use_lds': bool(ul.value), 'mode': mode.value, 'stream_bytes': sb.value, 'kernel': name}
+
+    def launch_ranges(self):
+        """First test-site index of every launch range of the selected slot's scan (bmx_ctx_launch_ranges)."""
+        n = C.c_int32()
+        _lib.check(self._L.bmx_ctx_launch_ranges(self._h, None, 0, C.byref(n)))
+        offs = np.zeros(max(n.value, 1), dtype=np.int64)
+        _lib.check(self._L.bmx_ctx_launch_ranges(self._h, _lib.as_lp(offs), len(offs), C.byref(n)))
+        return offs[:n.value]
 
     def pack_records(self, out=None, device_ptr=None, cap=None):
         """Records of every slot with results, slot order.  Host: returns a RECORD array.  device_ptr/cap: packs into

@@ -35,7 +35,7 @@ sys.path.insert(0, REPO)
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6300 achievable)
 SURVEY_FLOP_PER_EVAL = 32        # SURVEY.md 8(d) convention for the reference's FMA + log1p form
-CALIBRATION = os.path.join(REPO, 'profiles', 'r03_pmc_calibration.json')
+CALIBRATION = os.path.join(REPO, 'profiles', 'r04_pmc_calibration.json')
 
 
 def parse_args(argv=None):
@@ -55,6 +55,9 @@ def parse_args(argv=None):
     ap.add_argument('--variant', type=int, default=0)
     ap.add_argument('--step', type=int, default=1, help='test site = every step-th SNP (the reference\'s -s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cold-pass', action='store_true', help='skip the cold end-to-end pass after the timed steps (PMC runs: the counters '
+                                                                'must see exactly the timed step)')
+    ap.add_argument('--no-parity-sample', action='store_true', help='skip the oracle check of 256 windows of the last step (outside the timed region)')
     ap.add_argument('--cpu-seconds', type=float, default=24.0, help='budget of the faithful CPU port (both legs together)')
     return ap.parse_args(argv)
 
@@ -165,6 +168,36 @@ def _cpu_info():
     return model, avail
 
 
+def _pool_size(avail):
+    """Workers of the multiprocess leg: every CPU this process may run on (nproc-way), within the container's CPU
+    quota and with room in memory for one model per worker (~0.4 GB: the arrays of one chromosome + numpy/scipy)."""
+    n = max(1, int(avail))
+    try:                                   # cgroup v2 CPU quota, if any
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    mem = None
+    try:
+        v = open('/sys/fs/cgroup/memory.max').read().strip()
+        if v != 'max':
+            mem = int(v)
+    except (OSError, ValueError):
+        pass
+    try:
+        for l in open('/proc/meminfo'):
+            if l.startswith('MemAvailable'):
+                kb = int(l.split()[1]) * 1024
+                mem = kb if mem is None else min(mem, kb)
+                break
+    except (OSError, ValueError):
+        pass
+    if mem:
+        n = min(n, max(1, int(mem * 0.5 / 0.4e9)))
+    return n
+
+
 def cpu_baseline(specs, sizes, budget_s):
     """Times the ORACLE on this box's host cores (reported baseline, never the product path): the faithful port of
     calcBaller (BalLeRMix+_v1.py:436-507), single process (= what upstream does) and nproc-way multiprocess over windows
@@ -214,7 +247,7 @@ def cpu_baseline(specs, sizes, budget_s):
     # nproc-way: the same function, one window per task, over a process pool (workers rebuild the model from the recipe;
     # spawned, not forked: this process has the GPU open)
     try:
-        nproc = max(1, min(avail, 16))
+        nproc = _pool_size(avail)
         nwin = max(nproc, int(nproc * max(1.0, (budget_s * 0.35) / per_window[picks.index(mid)])))
         N = int(sizes[mid])
         idx = [int(v) for v in np.linspace(0, N - 1, nwin + 2).astype(int)[1:-1]]
@@ -229,6 +262,7 @@ def cpu_baseline(specs, sizes, budget_s):
         rate_mid = len(idx) / wall
         scale = float(t_of[mid]) * rate      # whole-workload rate / middle-chromosome rate of the single-process fit
         out['multiprocess'] = {'value': rate_mid * scale, 'unit': 'windows/s', 'cores': nproc,
+                               'cpu_quota': 'pool = every CPU this process may use: %d hardware threads visible, cgroup cpu.max allows %d' % (avail, nproc),
                                'sample': '%d windows on %d SNPs over a %d-process pool: %.1f windows/s there (%.2f s per window '
                                          'inside a worker, pool start-up %.1f s outside the clock); scaled to the workload by the '
                                          'single-process fit' % (len(idx), N, nproc, rate_mid, float(np.mean(times)), t_start)}
@@ -236,6 +270,54 @@ def cpu_baseline(specs, sizes, budget_s):
         out['multiprocess'] = {'error': repr(e)}
     out['seconds'] = time.time() - t_all
     return out
+
+
+def parity_sample(chroms, model, spect, props, min_count, xs, ab, As, step, world_size, layout, last, nwin=256):
+    """CHECKER, outside the timed region: `nwin` windows of the last step's results, spread over every chromosome, recomputed
+    by the plain-C oracle (oracle/bmx_oracle.c: calcBaller, BalLeRMix+_v1.py:436-507) from the ORACLE's own selection table
+    (oracle/bmx_oracle.py sel_table: NormalizedBetaBinom, v1:319-433) -- so a fast number from a broken kernel cannot be
+    printed unnoticed.  Returns the dict that goes into the JSON line."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    from util import c_oracle, c_scan, oracle_R
+    from ballermixplus_amd import distributed
+    t0 = time.time()
+    R = oracle_R('B2', sorted(props), min_count, spect, props, xs, ab)
+    L = c_oracle()
+    nx, nab = len(xs), len(ab)
+    per = max(1, nwin // len(chroms))
+    base = np.zeros(world_size, dtype=np.int64)       # where this chromosome's records start in each rank's buffer
+    worst, worst_abs, n, bad = 0.0, 0.0, 0, []
+    for ci, (gen, k, nn) in enumerate(chroms):
+        Nc = len(gen)
+        tidx = np.arange(0, Nc, step)
+        cnts = layout[ci]
+        pick = np.unique(np.linspace(0, len(tidx) - 1, per).astype(np.int64))
+        if world_size > 1:
+            parts = distributed.assign(len(tidx), world_size)
+        rec = np.empty(len(pick), dtype=last[0].dtype)
+        for q, j in enumerate(pick):
+            if world_size == 1:
+                rec[q] = last[0][base[0] + j]
+            else:
+                r = int((j // distributed.BLOCK) % world_size)
+                rec[q] = last[r][base[r] + int(np.searchsorted(parts[r], j))]
+        base += np.asarray(cnts, dtype=np.int64)
+        t = gen[tidx[pick]]
+        oc, ox, oa, oA, on = c_scan(L, R, As, gen, model.rows_of(k, nn), t, np.zeros(len(t), np.int64), np.full(len(t), Nc - 1, np.int64))
+        olin = np.where(oA < 0, -1, (oA * nx + ox) * nab + oa)
+        err = np.abs(rec['clr'] - oc)
+        ok = (rec['lin'] == olin) & (rec['nsites'] == on) & (err <= np.maximum(1e-9, 1e-6 * np.abs(oc)))
+        for q in np.where(~ok)[0][:4]:
+            bad.append({'chromosome': ci + 1, 'test_site': int(tidx[pick[q]]), 'clr': float(rec['clr'][q]), 'oracle_clr': float(oc[q]),
+                        'lin': int(rec['lin'][q]), 'oracle_lin': int(olin[q]), 'nsites': int(rec['nsites'][q]), 'oracle_nsites': int(on[q])})
+        worst = max(worst, float(np.max(err / np.maximum(np.abs(oc), 1e-9))))
+        worst_abs = max(worst_abs, float(err.max()))
+        n += len(t)
+    return {'windows': n, 'chromosomes': len(chroms), 'max_rel': worst, 'max_abs': worst_abs, 'mismatches': len(bad), 'first_mismatches': bad[:8],
+            'seconds': time.time() - t0,
+            'checker': 'oracle/bmx_oracle.c orc_scan on the oracle\'s own table (oracle/bmx_oracle.py sel_table); exact (x, alpha, A, nSites), '
+                       'CLR to 1e-6 relative (1e-9 floor); outside the timed region'}
 
 
 class _QuietStdout:
@@ -458,7 +540,36 @@ def _run(args):
         k_total = float(sum(kernel_ms))
 
     if rank == 0:
+        last = [np.array(g, copy=True) for g in last]       # the cold pass below reuses the transfer buffers
+    # ---- one COLD pass, outside the timed steps: a fresh context given host buffers -- table build (K1), uploads, test-site
+    # location, the planning / counting pass, the scans, the result transfer (what a caller of the C ABI pays once per genome)
+    t_cold, cold = None, None
+    if not args.no_cold_pass:
+        ctx.close()
+        barrier()
+        t0 = time.perf_counter()
+        ctx = engine.Context(dev)
+        ctx.set_variant(args.variant)
+        ctx.set_model(model, As)
+        for ci, (gen, k, nn) in enumerate(chroms):
+            Nc = len(gen)
+            tidx = np.arange(0, Nc, args.step)
+            mine = tidx[distributed.assign(len(tidx), world.size)[rank]] if sharded else tidx
+            ctx.select_slot(ci)
+            ctx.set_sites(gen, model.rows_of(k, nn))
+            if len(mine):
+                ctx.set_tests(gen[mine], np.zeros(len(mine), np.int64), np.full(len(mine), Nc - 1, np.int64))
+        cold = one_step()
+        barrier()
+        t_cold = time.perf_counter() - t0
+    if world.distributed and t_cold is not None:
+        tc = torch.tensor([t_cold], dtype=torch.float64, device=tdev if on_gpu else torch.device('cpu'))
+        torch.distributed.all_reduce(tc, op=torch.distributed.ReduceOp.MAX)
+        t_cold = float(tc[0].item())
+
+    if rank == 0:
         checksum = float(sum(float(np.sum(g['clr'])) for g in last))
+        cold_same = cold is not None and all(np.array_equal(a, b) for a, b in zip(last, cold))
         nrec = int(sum(len(g) for g in last))
         k_step_s = k_total / args.steps * 1e-3                     # scan kernels of one step (slowest rank)
         windows = float(windows_per_step) * args.steps
@@ -499,6 +610,11 @@ def _run(args):
                        'kernel_ms_per_step': k_step_s * 1e3,
                        'records_per_step': nrec,
                        'checksum_clr': checksum,
+                       'end_to_end_windows_per_s': windows_per_step / t_cold if t_cold else None,
+                       'end_to_end_seconds': t_cold,
+                       'end_to_end_note': 'one cold pass outside the timed steps: fresh context from host buffers -- table build (K1), '
+                                          'H2D of all site arrays and test sites, test-site location + planning / counting pass, the scans, the '
+                                          'result records to the host (N > 1: the gather); records bitwise equal to the timed steps\': %s' % cold_same,
                        'input_sha256': digest.hexdigest(),
                        'library_build': build_id,
                        'plan_seconds_outside_timed_region': t_plan,
@@ -510,9 +626,10 @@ def _run(args):
                 'evals_per_step': evals_per_step, 'evals_per_s': evals_s,
                 'survey_convention_tflops': evals_s * SURVEY_FLOP_PER_EVAL / 1e12,
                 'note': 'The scan is bound by vector-instruction issue, not by HBM or MFMA (no contraction on this path). '
-                        'achieved/frac: executed VALU wave-instructions x 128 flop / kernel time against the vector FP64 peak = the '
-                        'share of the chip\'s vector issue slots the scan kernels fill (every VALU instruction, FP64 or not, takes one slot). '
-                        'fp64_flops_frac: the FP64 arithmetic alone (FMA = 2 flop, MUL/ADD = 1 per lane) against the same peak. Both use '
+                        'achieved/frac: the FP64 arithmetic the scan kernels execute (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64: FMA = 2 flop, MUL/ADD = 1 '
+                        'per lane) / kernel time against the vector FP64 peak. valu_issue_frac: ALL executed VALU wave-instructions x 128 '
+                        'flop-equivalents against the same peak = the share of the chip\'s vector issue slots the kernels fill (every VALU '
+                        'instruction, FP64 or not, takes one slot) -- an occupancy figure, not a flop rate. Both use '
                         'per-evaluation instruction counts measured with rocprofv3 PMC passes on THIS library build (calibration) x '
                         'evaluations per second measured here with HIP events; null when the calibration is for another kernel or build. '
                         'kernel_ms: HIP events around each chromosome\'s launches (per-group preparation kernel + scan kernel + finalize) on the '
@@ -527,12 +644,13 @@ def _run(args):
         }
         if cal:
             r = res['roofline']
-            r['valu_insts_per_64_evals'] = cal['valu_per_64_evals']
-            r['achieved'] = evals_s * cal['valu_per_64_evals'] * 128 / 64 / 1e12
-            r['frac'] = r['achieved'] / FP64_VALU_PEAK_TFLOPS
             r['fp64_flops_per_eval'] = cal['fp64_flops_per_eval']
-            r['fp64_tflops'] = evals_s * cal['fp64_flops_per_eval'] / 1e12
-            r['fp64_flops_frac'] = r['fp64_tflops'] / FP64_VALU_PEAK_TFLOPS
+            r['achieved'] = evals_s * cal['fp64_flops_per_eval'] / 1e12          # FP64 flop actually executed per second
+            r['frac'] = r['achieved'] / FP64_VALU_PEAK_TFLOPS
+            r['fp64_tflops'], r['fp64_flops_frac'] = r['achieved'], r['frac']    # (the names round 3's line used)
+            r['valu_insts_per_64_evals'] = cal['valu_per_64_evals']
+            r['valu_issue_tflops_equiv'] = evals_s * cal['valu_per_64_evals'] * 128 / 64 / 1e12
+            r['valu_issue_frac'] = r['valu_issue_tflops_equiv'] / FP64_VALU_PEAK_TFLOPS
             r['calibration'] = cal['source']
             # HBM traffic of one average launch, from the PMC counters per window (FETCH_SIZE doubled as the guide
             # prescribes for gfx950, WRITE_SIZE as read)
@@ -542,6 +660,16 @@ def _run(args):
             res['roofline_hbm']['measured_hbm_gbs'] = per_window * windows_per_step / k_step_s / 1e9
         else:
             res['roofline']['calibration_warning'] = why
+        if not args.no_parity_sample and not args.n_spread:
+            try:
+                ps = parity_sample(chroms, model, spect, props, min_count, xs, ab, As, args.step, world.size, layout, last)
+                res['parity_sample'] = ps
+                res['parity_sample_max_rel'] = ps['max_rel']
+                if ps['mismatches']:
+                    res['parity_sample_FAILED'] = True
+                    sys.stderr.write('bench.py: PARITY SAMPLE FAILED: %r\n' % (ps['first_mismatches'],))
+            except Exception as e:
+                res['parity_sample'] = {'error': repr(e)[:500]}
         if not args.no_cpu_baseline and world.size == 1:      # reported baseline: rank 0, N = 1 only
             specs = [(int(Nc), int(n), int(cid), spect, props, min_count, args.config == 5) for cid, Nc in zip(chrom_ids, sizes_c)]
             if args.n_spread:

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define BMX_ABI_VERSION_MAJOR 1
-#define BMX_ABI_VERSION_MINOR 2
+#define BMX_ABI_VERSION_MINOR 3
 
 enum {
     BMX_OK = 0,
@@ -196,6 +196,11 @@ int bmx_ctx_pack_records(bmx_ctx *c, void *dst, int64_t cap, int32_t dst_on_devi
  * sparse or unsorted test sites), 0..3 the round-2 grouped forms, -1 the round-2 per-site kernel; *stream_bytes = bytes of the prepared
  * per-group streams of all test sites (0 otherwise).  Any pointer may be NULL. */
 int bmx_ctx_plan(bmx_ctx *c, int32_t *J, int32_t *use_lds, int32_t *mode, int64_t *stream_bytes);
+/* Where the selected slot's scan is cut into launches: offs[i] = index of the first test site of launch range i (offs[0] = 0;
+ * range i ends where range i + 1 begins, the last one at M).  At most `cap` entries are written; *n_out = number of ranges.
+ * A window's result must not depend on the cut -- the parity tests compare the windows on either side of every cut
+ * with the oracle.  Valid once the test sites are set. */
+int bmx_ctx_launch_ranges(bmx_ctx *c, int64_t *offs, int32_t cap, int32_t *n_out);
 
 /* ---- input ingest (host only) ------------------------------ */
 /* Native reader of the 4-column input that InputData.readCounts / readPolyCalls parse line by

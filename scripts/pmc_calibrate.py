@@ -1,5 +1,5 @@
 """Turns the counter CSVs of scripts/pmc_collect.sh into the per-evaluation / per-window figures bench.py's roofline uses.
-    python scripts/pmc_calibrate.py <tag> <dir>     -> prints a summary and the JSON entry for profiles/r03_pmc_calibration.json
+    python scripts/pmc_calibrate.py <tag> <dir>     -> prints a summary and the JSON entry for profiles/r04_pmc_calibration.json
 All counters are summed over the dispatches of the scan kernels (the per-group preparation kernel prep_kernel<J,true> and
 the pair-parallel kernel clr_scan_*) in one bench step -- the counting pass prep_kernel<J,false> runs when the test sites
 are set, outside the step, and is listed separately; evaluations and windows of that step come from the bench line of the
@@ -7,7 +7,7 @@ same process (evals_per_step: sum over test sites of |x| |alpha| sum_A W_A, SURV
 import collections, csv, glob, json, os, sys
 
 tag, root = sys.argv[1], sys.argv[2]
-key = sys.argv[3] if len(sys.argv) > 3 else 'config' + tag.strip('c')      # entry name in profiles/r03_pmc_calibration.json
+key = sys.argv[3] if len(sys.argv) > 3 else 'config' + tag.strip('c')      # entry name in profiles/r04_pmc_calibration.json
 tot = collections.defaultdict(float)
 per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))
 ndisp = {}
@@ -98,6 +98,6 @@ entry = {
     'valu_share_of_preparation_kernel': per_kernel['prep'].get('SQ_INSTS_VALU', 0.0) / valu if valu else None,
     'kernel_ms_profiled': dur,
     'source': 'rocprofv3 --pmc passes A-E of `python3 bench.py %s --steps 1 --warmup 0 --no-cpu-baseline` (scripts/pmc_collect.sh %s), '
-              'profiles/r03_pmc_%s_summary.txt' % (' '.join(bench.get('argv', [])) or '--config ' + tag.strip('c'), tag, tag),
+              'profiles/r04_pmc_%s_summary.txt' % (' '.join(bench.get('argv', [])) or '--config ' + tag.strip('c'), tag, tag),
 }
 print(json.dumps({key: entry}, indent=1))

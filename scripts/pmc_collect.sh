@@ -2,14 +2,14 @@
 # Collects the rocprofv3 evidence behind bench.py's roofline (run on the GPU box, from the repo root):
 #   [PMC_KEY=config3_step64] bash scripts/pmc_collect.sh <tag> <bench args...>      e.g.  bash scripts/pmc_collect.sh c3 --config 3
 # One process per counter group (the SQ block has 8 slots, FETCH_SIZE and WRITE_SIZE do not fit one TCC pass), each with
-# --kernel-trace so that the dispatch list comes with it; the program sits directly behind `--`.  Output: gpurun_out/r03/<tag>/.
+# --kernel-trace so that the dispatch list comes with it; the program sits directly behind `--`.  Output: gpurun_out/${ROUND:-r04}/<tag>/.
 set -u
 TAG=$1; shift
 R=$(pwd)
-OUT=$R/gpurun_out/r03/$TAG
+OUT=$R/gpurun_out/${ROUND:-r04}/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$* --steps 1 --warmup 0 --no-cpu-baseline"
+ARGS="$* --steps 1 --warmup 0 --no-cpu-baseline --no-cold-pass --no-parity-sample"
 pass() {   # name, counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $R/bench.py $ARGS > $OUT/$name.json 2> $OUT/$name.err

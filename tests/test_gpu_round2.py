@@ -3,6 +3,7 @@ streaming writer, the 16-byte records, the result-state guard, the multi-rank CL
 configs 4 and 5 at their full per-chromosome sizes (whole-genome run on one context, reference windows on the
 chromosomes the reference could afford)."""
 import ctypes as C
+import functools
 import hashlib
 import os
 import subprocess
@@ -316,6 +317,7 @@ def test_bench_contract_two_ranks_on_one_gpu():
 
 
 # ------------------------------------------------------------------------------------------------ configs 4 and 5 at size
+@functools.lru_cache(maxsize=1)
 def _config4_data():
     from ballermixplus_amd import synth
     sizes = synth.config4_sizes(40_000_000)

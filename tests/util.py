@@ -72,6 +72,21 @@ def c_scan(L, R, As, genpos, row, test_gen, lo, hi):
     return clr, ix, ia, iA, ns
 
 
+def oracle_R(stat, sizes, min_count, spect, props, xs, abetas):
+    """R[nx][nab][rows] = P_sel * prop / g - 1 built by the ORACLE alone (oracle/bmx_oracle.py sel_table: scipy's betabinom,
+    as the reference calls it, v1:319-433) -- nothing from the GPU's K1, so that a scan compared against c_scan(R=this) is
+    checked K1 -> K2 -> finalize end to end.  Rows: one block of n + 1 per sample size, ascending n (2 for B_1)."""
+    tabs, g, pr = [], [], []
+    for n in sorted(int(v) for v in sizes):
+        t = orc.sel_table(stat, n, min_count, list(xs), list(abetas))
+        tabs.append(t)
+        for k in range(t.shape[2]):
+            g.append(spect.get((k, n), np.nan))
+            pr.append(props[n])
+    with np.errstate(invalid='ignore', divide='ignore'):
+        return np.concatenate(tabs, axis=2) * np.array(pr) / np.array(g) - 1.0
+
+
 def stat_of(nofreq, MAF, nosub):
     if nofreq:
         return 'B1'
