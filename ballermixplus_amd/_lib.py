@@ -72,6 +72,7 @@ PROTOTYPES = {
     'bmx_ctx_select_slot': (C.c_int, [_vp, C.c_int32]),
     'bmx_ctx_slot_count': (C.c_int, [_vp]),
     'bmx_ctx_pack_records': (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, _lp]),
+    'bmx_ctx_copy_records': (C.c_int, [_vp, _vp, C.c_int64]),
     'bmx_ctx_plan': (C.c_int, [_vp, _ip, _ip, _ip, _lp]),
     'bmx_ctx_launch_ranges': (C.c_int, [_vp, _lp, C.c_int32, _ip]),
     'bmx_ctx_surface': (C.c_int, [_vp, C.c_double, C.c_int64, C.c_int64, _dp, _ip]),
@@ -107,7 +108,10 @@ def lib():
             raise ImportError('libbmxscan.so not built: %s is missing. Run `make -C %s` '
                               '(needs hipcc); there is no CPU fallback.' % (LIB_PATH, os.path.join(_HERE, 'csrc')))
         L = C.CDLL(LIB_PATH)
+        lenient = os.environ.get('BMX_ALLOW_STALE') == '1'       # A/B runs against older builds: entry points they lack stay unbound
         for name, (res, args) in PROTOTYPES.items():
+            if lenient and not hasattr(L, name):
+                continue
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -89,8 +89,10 @@ def main(argv=None):
         parser.error('the following arguments are required: -i/--input')
     files = None
     if opt.inputs is not None:
-        with open(opt.inputs) as f:
-            files = [l.strip() for l in f if l.strip() and not l.startswith('#')]
+        if opt.getSpec or opt.getConfig:
+            print('--inputs lists files to scan; --getSpect / --getConfig take ONE concatenated input with -i (as in the reference).')
+            sys.exit(1)
+        files = input_list(opt.inputs)
     elif ',' in opt.infile and not os.path.exists(opt.infile):
         files = [p for p in opt.infile.split(',') if p]
     if files is not None and not (opt.getSpec or opt.getConfig):
@@ -157,16 +159,38 @@ def main(argv=None):
     say(("\n%s. Start computing likelihood ratios..." % (datetime.now())))
     # BMX_SHARD_BLOCK: test sites per shard block (default distributed.BLOCK = 4096; a multiple of 16 keeps every window's
     # arithmetic independent of the number of ranks) -- lets small inputs exercise real sharding in the tests
-    block = int(os.environ['BMX_SHARD_BLOCK']) if os.environ.get('BMX_SHARD_BLOCK') else None
-    if block is not None and (block < 16 or block % 16):
-        print('BMX_SHARD_BLOCK must be a positive multiple of 16.')
-        sys.exit(1)
-    runner = world.sharded_runner(block=block) if world.distributed else None
+    runner = world.sharded_runner(block=shard_block()) if world.distributed else None
     Scan(data, Neutral, Sel_Probs, grid, opt.outfile if world.rank == 0 else None, fixSize=opt.size, r=opt.w,
          s=opt.step, phys=opt.phys, noCenter=opt.noCenter, runner=runner, verbose=verbose, keep_results=False)
     stamp('table, scan, output')
     world.finish()
     say(f'\n{datetime.now()}. Pipeline finished.')
+
+
+def shard_block():
+    """BMX_SHARD_BLOCK: test sites per shard block of a multi-rank run (default distributed.BLOCK = 4096).  A multiple of 16
+    keeps group boundaries -- hence every window's arithmetic -- independent of the number of ranks; small values let small
+    inputs exercise real sharding in the tests."""
+    v = os.environ.get('BMX_SHARD_BLOCK')
+    if not v:
+        return None
+    try:
+        block = int(v)
+    except ValueError:
+        block = 0
+    if block < 16 or block % 16:
+        print('BMX_SHARD_BLOCK must be a positive multiple of 16.')
+        sys.exit(1)
+    return block
+
+
+def input_list(path):
+    """The files named in an --inputs list: one per line, blank lines and lines starting with # skipped, relative names taken
+    relative to the list's own directory."""
+    here = os.path.dirname(os.path.abspath(path))
+    with open(path) as f:
+        names = [l.strip() for l in f]
+    return [n if os.path.isabs(n) else os.path.join(here, n) for n in names if n and not n.startswith('#')]
 
 
 def output_name(outspec, infile):
@@ -206,14 +230,14 @@ def main_many(opt, files, stamp=lambda what: None):
     if len(set(outs)) != len(outs):
         print('Two input files map to the same output name; give -o a pattern with {} or distinct basenames.')
         sys.exit(1)
-    if world.rank == 0 and '{}' not in opt.outfile:
-        os.makedirs(opt.outfile, exist_ok=True)
+    if world.rank == 0:
+        for d in sorted(set(os.path.dirname(os.path.abspath(o)) for o in outs)):
+            os.makedirs(d, exist_ok=True)
     grid = Grids(opt.x, opt.abeta, opt.bal, opt.pos, opt.seqA, opt.listA)
     say('\nOptimizing over x= ' + ', '.join(['%g' % (x) for x in grid.x]))
     say('\n \t alpha= ' + ', '.join([str(a) for a in grid.abeta]))
     say('\n \t A= ' + ', '.join([str(A) for A in grid.A]))
-    block = int(os.environ['BMX_SHARD_BLOCK']) if os.environ.get('BMX_SHARD_BLOCK') else None
-    runner = world.sharded_runner(block=block) if world.distributed else None
+    runner = world.sharded_runner(block=shard_block()) if world.distributed else None
     nxt = {}
 
     def host_stage(i):
@@ -243,7 +267,7 @@ def main_many(opt, files, stamp=lambda what: None):
             th.start()
         say(f"\n{datetime.now()}. {infile} -> {outfile}")
         Scan(data, neut, sel, grid, outfile if world.rank == 0 else None, fixSize=opt.size, r=opt.w, s=opt.step, phys=opt.phys,
-             noCenter=opt.noCenter, runner=runner, verbose=False, keep_results=False, reuse_ctx=ctx)
+             noCenter=opt.noCenter, runner=runner, verbose=verbose, keep_results=False, reuse_ctx=ctx)
         ctx = sel.ctx
         tables += 0 if sel.table_reused else 1
         try:

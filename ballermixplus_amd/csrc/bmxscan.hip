@@ -39,6 +39,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 #include <string>
 #include <thread>
@@ -110,7 +111,7 @@ constexpr int MOM_SLOTS_LDS = 64;             // ... of which this many are used
 #define BMX_XCD_MAP 1     // prepared kernel: the slices of a chunk of test sites on one XCD (4.168 -> 4.205 M windows/s, HBM reads / 8)
 #endif
 #ifndef BMX_SOLO_XCD_MAP
-#define BMX_SOLO_XCD_MAP 0     // measured: no change for the solo kernel (1.219 vs 1.216 M windows/s)
+#define BMX_SOLO_XCD_MAP 1     // the slices of a chunk of test sites on one XCD: the chunk's streams come out of HBM once, not eight times
 #endif
 #ifndef BMX_PRIV01
 #define BMX_PRIV01 1
@@ -382,6 +383,17 @@ __device__ __forceinline__ void renorm(double &acc, int &E) {
     E = (e == 0) ? -(1 << 28) : E + (e - 1023);
     hi = (hi & 0x800fffffu) | 0x3ff00000u;
     acc = __hiloint2double((int)hi, __double2loint(acc));
+}
+
+// The same with the hardware's frexp pair (v_frexp_exp_i32_f64 / v_frexp_mant_f64): three VALU instructions instead of six.  The
+// mantissa lands in [1/2, 1) -- a convention of its own: whoever compares (exponent, mantissa) pairs must take both from this
+// function -- and a zero product keeps mantissa 0 with its exponent unchanged, so the comparison has to ask for a positive mantissa.
+#ifndef BMX_FREXP
+#define BMX_FREXP 0     // prepared kernels: measured no gain (config-3 block 4.45 vs 4.43 M windows/s), so they keep the integer form
+#endif
+__device__ __forceinline__ void renorm_fx(double &acc, int &E) {
+    E += __builtin_amdgcn_frexp_exp(acc);
+    acc = __builtin_amdgcn_frexp_mant(acc);
 }
 
 // One (E or alpha, row * 64) entry of a wave's scratch list in LDS: written lanes-over-sites, read back with a uniform
@@ -1355,10 +1367,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_grouped_kernel(Scan
 //                  near list: n_pair entries with alpha > 1/2 (padded to whole blocks), then n_quad entries (multiple of 4),
 //                             each (E_i f64, row offset i32), in walk order; 8 neutral guard entries (what the block loops
 //                             request one block ahead)
+//                  ragged end (rag only): n_rag entries (E, row offset, flag) + 1 guard   (round 4: here, not behind the far field)
 //   far(zone)    = moments:   n_occ entries of PREP_MOM units: (M_1, row offset) (M_2, M_3) (M_4, M_5) ...
 //                  series entries: n_ser (a multiple of 4, <= 64) entries (E, row offset, order class) of far sites whose row has no
 //                                  moment slot, highest class first
-//                  ragged end (rag only): n_rag entries (E, row offset) + 1 guard
 //   (both near lists first: the consumer multiplies, then takes ONE exp per test site for the two far fields together)
 // Sizes come from a counting pass of the same code (prep_kernel<J, false>: identical predicates, no exp, no stores) run when
 // the test sites are set, then an exclusive scan; the fill pass (prep_kernel<J, true>) and the consumer run per launch range.
@@ -1640,6 +1652,14 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                     rag = __ballot(far8) == ~0ull ? (__ballot(far3) == ~0ull ? 1 : 3) : 0;
                 }
             }
+            // the ragged end's entries follow the near list (the consumer walks them there, before either far field)
+            if (rag) {
+                if (FILL) {
+                    if (lane < nrmax) out[wpos + lane] = ScratchEnt{exp_neg(zr), rr * P.rowmul, zr >= thr_of(rr) + P_RAG_D ? 0 : 1};      // 1: orders 4..8 too
+                    if (lane == nrmax) out[wpos + lane] = ScratchEnt{0.0, rr * P.rowmul, 0};
+                }
+                wpos += nrmax + PREP_RAG_GUARD;
+            }
             zbase_o = zbase; npp_o = n_pair_pad; nqp_o = n_quad_pad; nfar_o = nfar_tot; base_o = base; m1p_o = m1p; m2p_o = m2p;
             nragv_o = nrag_v; nrmax_o = nrmax; rag_o = rag; zr_o = zr; rr_o = rr; nser_o = n_ser;
         };
@@ -1724,13 +1744,6 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_kernel(PrepParams P) {
                 }
                 wpos += n_ser_pad;
             }
-            if (rag) {
-                if (FILL) {
-                    if (lane < nrmax) out[wpos + lane] = ScratchEnt{exp_neg(zr), rr * P.rowmul, zr >= thr_of(rr) + P_RAG_D ? 0 : 1};      // 1: orders 4..8 too
-                    if (lane == nrmax) out[wpos + lane] = ScratchEnt{0.0, rr * P.rowmul, 0};
-                }
-                wpos += nrmax + PREP_RAG_GUARD;
-            }
             if (FILL) {
                 // n_j of the J test sites as bytes (n_j < 64)
                 int w = nrag_v & 0xff;
@@ -1803,6 +1816,9 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
     long long tprev_ = clock64();
 #endif
     extern __shared__ __attribute__((aligned(16))) double lds_R[];  // [rows][64] when USE_LDS, then per wave: ring + scratch, sites between the test sites
+    // farg[j] as an LLVM vector: the ragged-end walk indexes it with a wave-uniform j, which the compiler turns into GPR indexing
+    // (s_set_gpr_idx_on) -- a C array indexed dynamically would live in scratch memory
+    typedef double FargVec __attribute__((ext_vector_type(J)));
     constexpr int SP = WAVE / J;
     constexpr int BS = J >= 16 ? 4 : 8;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1919,7 +1935,10 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
         double acc[J], bestM[J];
         int E[J], bestK[J];
 #pragma unroll
-        for (int j = 0; j < J; ++j) { bestM[j] = 1.0; bestK[j] = (131072 << 13) | 8191; }
+        for (int j = 0; j < J; ++j) {        // the product 1 (T = 0: only a larger one wins, v1:451,501) in the convention of the renormalisation
+            bestM[j] = BMX_FREXP ? 0.5 : 1.0;
+            bestK[j] = ((131072 + (BMX_FREXP ? 1 : 0)) << 13) | 8191;
+        }
 
         for (int iA = 0; iA < P.nA; ++iA) {
             const double A = P.A[iA];
@@ -1928,7 +1947,9 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
             for (int j = 0; j < J; ++j) { acc[j] = 1.0; E[j] = 0; }
             auto renorm_all = [&]() {
 #pragma unroll
-                for (int j = 0; j < J; ++j) renorm(acc[j], E[j]);
+                for (int j = 0; j < J; ++j) {
+                    if (BMX_FREXP) renorm_fx(acc[j], E[j]); else renorm(acc[j], E[j]);
+                }
                 bits = 0;
             };
             auto spend = [&](int nbits) {
@@ -1989,9 +2010,11 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
 
             // One zone of the blob, first half: header and near-list products; returns where the generic walk goes on.  What
             // the far half needs later (after BOTH near lists) comes back through the references; fv: lane j holds F_j.
-            auto zone_near = [&](int dir, double tnear, double &fv_o, int &nocc_o, int &nfar_o, int &nrmax_o, int &rag_o, int &nragv_o,
-                                 int &nser_o) -> int {
-                nocc_o = 0; nfar_o = 0; nrmax_o = 0; rag_o = 0; nragv_o = 0; nser_o = 0;
+            auto zone_near = [&](auto dirk, double tnear, double &fv_o, int &nocc_o, int &nfar_o, int &nrmax_o, int &rag_o, int &nser_o,
+                                 FargVec &farg) -> int {
+                constexpr int dirc = decltype(dirk)::value;       // compile-time: farg[j] and F[j] of the ragged-end walk are registers
+                int nragv_o = 0;
+                nocc_o = 0; nfar_o = 0; nrmax_o = 0; rag_o = 0; nser_o = 0;
                 fv_o = 0.0;
                 if (bad) return PREP_ZONE_DONE;
                 double F[J];
@@ -2121,16 +2144,66 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 }
                 PROF_MARK(3);
                 pos += PREP_GUARD;
+                // The ragged end (< 64 entries and a guard) follows the near list in the stream: read at once, lanes over entries; the walk
+                // takes an entry out of the registers and has its R loaded ahead.  Test site by test site, in the order in which the
+                // windows end: its share of the entries into three sums of their own (third-order Taylor terms: these sites sit at
+                // A d ~ 18.4), then the sums as they stand into farg[j].  Done HERE, where only the running products are live -- not
+                // between the Horner chains of the far field, where round 3 had it and paid 49 spilled registers for it.
+                if (rag) {
+                    need();
+                    const bool rag_hi = (rag & 2) != 0;
+                    const ScratchEnt ragm = ring[(pos + lane) & (RING_UNITS - 1)];
+                    double rag_R0 = loadR(__builtin_amdgcn_readlane(ragm.ro, 0));
+                    double rag_R1 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(1, nrmax)));
+                    double rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(2, nrmax)));
+                    const int nrag_v = nragv_o;
+                    double r1 = 0.0, r2 = 0.0, r3 = 0.0;
+                    int l = 0;
+#pragma nounroll
+                    for (int w = 0; w < J; ++w) {
+                        const int j = dirc > 0 ? w : J - 1 - w;
+                        const int nj = __builtin_amdgcn_readlane(nrag_v, j);
+                        for (; l < nj; ++l) {
+                            const double v = readlane_f64(ragm.e, l) * rag_R0, v2 = v * v;
+                            rag_R0 = rag_R1;
+                            rag_R1 = rag_R2;
+                            rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(l + 3, nrmax)));     // (the guard at the end)
+                            r1 += v;
+                            r2 = fma(v2, 0.5, r2);
+                            r3 = fma(v2 * v, 0.3333333333333333, r3);
+                        }
+                        const double f = readlane_f64(fv_o, j);
+                        farg[j] = fma(-f, fma(-f, fma(-f, r3, r2), r1), farg[j]);
+                    }
+                    // (rare) sites of the ragged end with alpha max|R| between 3e-4 and 0.03, flagged by the producer: orders 4 to 8 of each, for
+                    // the test sites whose windows hold it -- apart from the walk above
+                    if (rag_hi) {
+                        for (int lh = 0; lh < nrmax; ++lh) {
+                            if (__builtin_amdgcn_readlane(ragm.pad, lh) == 0) continue;
+                            const double v = readlane_f64(ragm.e, lh) * loadR(__builtin_amdgcn_readlane(ragm.ro, lh));
+#pragma unroll
+                            for (int j = 0; j < J; ++j) {
+                                const double u = (lh < __builtin_amdgcn_readlane(nrag_v, j)) ? F[j] * v : 0.0;
+                                const double u2 = u * u;
+                                double t = fma(-u, P_W[7], P_W[6]);
+                                t = fma(-u, t, P_W[5]);
+                                t = fma(-u, t, P_W[4]);
+                                t = fma(-u, t, P_W[3]);
+                                farg[j] = fma(u2 * u2, t, farg[j]);
+                            }
+                        }
+                    }
+                    pos += nrmax + PREP_RAG_GUARD;
+                }
+                PROF_MARK(7);
                 return base_end;
             };
 
             // ... second half, after both zones' near lists: fold the zone's moments, walk its ragged end, and ADD the log of
             // the factor each test site's product has to pick up to farg (the exp is taken once for both zones)
-            auto zone_far = [&](auto dirc, double fv, int n_occ, int ser_w, int nfar_tot, int nrmax, int ragf, int nrag_v, double (&farg)[J]) {
-                const bool rag = (ragf & 1) != 0, rag_hi = (ragf & 2) != 0;
+            auto zone_far = [&](double fv, int n_occ, int ser_w, int nfar_tot, FargVec &farg) {
                 const int n_ser = ser_w & 0xff, ser_cls = ser_w >> 8;        // entries; cumulative class counts (8, 5, 3), 8 bits each
-                constexpr int dir = decltype(dirc)::value;        // compile-time: farg[j] and F[j] below are registers, not indexed memory
-                if (bad || !(nfar_tot || rag)) return;
+                if (bad || !nfar_tot) return;
                 double F[J];
 #pragma unroll
                 for (int j = 0; j < J; ++j) F[j] = readlane_f64(fv, j);
@@ -2236,95 +2309,17 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     pos += n_ser;
                 }
                 PROF_MARK(6);
-                need();
 #pragma unroll
                 for (int k = 0; k < P_ORDER; ++k) pk[k] *= P_W[k];
-                // the ragged end (< 64 entries and a guard): read at once, lanes over entries; the walk below takes an entry out of the
-                // registers and has its R loaded ahead.  (The rotation by moves waits for the newest load, so the distance is one step in
-                // effect; three registers taken in turn under a phase variable measured 5 % slower: r03 notes in DESIGN.md.)
-                int l = 0;
-                ScratchEnt ragm = ScratchEnt{0.0, 0, 0};
-                double rag_R0 = 0.0, rag_R1 = 0.0, rag_R2 = 0.0;
-                if (rag) {
-                    ragm = ring[(pos + lane) & (RING_UNITS - 1)];
-                    rag_R0 = loadR(__builtin_amdgcn_readlane(ragm.ro, 0));
-                    rag_R1 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(1, nrmax)));
-                    rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(2, nrmax)));
+                // the Horner chains of the zone's far field, one per test site, in one straight line
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const double f = F[j];
+                    double t = pk[P_ORDER - 1];
+#pragma unroll
+                    for (int k = P_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
+                    farg[j] = fma(-f, t, farg[j]);              // exp_neg's argument: the factor is exp(f t)
                 }
-                if (USE_LDS) {
-                    // test site by test site: its share of the ragged end into the power sums, then its Horner chain
-#pragma unroll
-                    for (int w = 0; w < J; ++w) {
-                        const int j = dir > 0 ? w : J - 1 - w;
-                        if (rag) {
-                            const int nj = __builtin_amdgcn_readlane(nrag_v, j);
-                            for (; l < nj; ++l) {
-                                const double v = readlane_f64(ragm.e, l) * rag_R0, v2 = v * v;
-                                rag_R0 = rag_R1;
-                                rag_R1 = rag_R2;
-                                rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(l + 3, nrmax)));     // (the guard at the end)
-                                pk[0] += v;
-                                pk[1] = fma(v2, 0.5, pk[1]);
-                                pk[2] = fma(v2 * v, 0.3333333333333333, pk[2]);
-                            }
-                        }
-                        const double f = F[j];
-                        double t = pk[P_ORDER - 1];
-#pragma unroll
-                        for (int k = P_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
-                        farg[j] = fma(-f, t, farg[j]);              // exp_neg's argument: the factor is exp(f t)
-                    }
-                } else {
-                    // the table in L2 / HBM: the sixteen Horner chains of the zone's common far field in one straight line, then the ragged
-                    // end in sums of its own, walked once and cut at n_j for test site j (0.6 % more instructions, 8 fewer spills: +2.7 %
-                    // here, -0.6 % with the table in LDS, which therefore keeps the form above)
-#pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        const double f = F[j];
-                        double t = pk[P_ORDER - 1];
-#pragma unroll
-                        for (int k = P_ORDER - 2; k >= 0; --k) t = fma(-f, t, pk[k]);
-                        farg[j] = fma(-f, t, farg[j]);
-                    }
-                    if (rag) {
-                        double r1 = 0.0, r2 = 0.0, r3 = 0.0;
-#pragma unroll
-                        for (int w = 0; w < J; ++w) {
-                            const int j = dir > 0 ? w : J - 1 - w;
-                            const int nj = __builtin_amdgcn_readlane(nrag_v, j);
-                            for (; l < nj; ++l) {
-                                const double v = readlane_f64(ragm.e, l) * rag_R0, v2 = v * v;
-                                rag_R0 = rag_R1;
-                                rag_R1 = rag_R2;
-                                rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(l + 3, nrmax)));     // (the guard at the end)
-                                r1 += v;
-                                r2 = fma(v2, 0.5, r2);
-                                r3 = fma(v2 * v, 0.3333333333333333, r3);
-                            }
-                            const double f = F[j];
-                            farg[j] = fma(-f, fma(-f, fma(-f, r3, r2), r1), farg[j]);
-                        }
-                    }
-                }
-                // (rare) sites of the ragged end with alpha max|R| between 3e-4 and 0.03, flagged by the producer: orders 4 to 8 of each, for
-                // the test sites whose windows hold it -- apart from the walk above, which stays what it was
-                if (rag_hi) {
-                    for (int lh = 0; lh < nrmax; ++lh) {
-                        if (__builtin_amdgcn_readlane(ragm.pad, lh) == 0) continue;
-                        const double v = readlane_f64(ragm.e, lh) * loadR(__builtin_amdgcn_readlane(ragm.ro, lh));
-#pragma unroll
-                        for (int j = 0; j < J; ++j) {
-                            const double u = (lh < __builtin_amdgcn_readlane(nrag_v, j)) ? F[j] * v : 0.0;
-                            const double u2 = u * u;
-                            double t = fma(-u, P_W[7], P_W[6]);
-                            t = fma(-u, t, P_W[5]);
-                            t = fma(-u, t, P_W[4]);
-                            t = fma(-u, t, P_W[3]);
-                            farg[j] = fma(u2 * u2, t, farg[j]);
-                        }
-                    }
-                }
-                if (rag) pos += nrmax + PREP_RAG_GUARD;
                 PROF_MARK(7);
             };
 
@@ -2377,20 +2372,20 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
             PROF_MARK(0);
             // right side, left side: near lists and whatever the zones do not cover
             double fvR, fvL;
-            int noccR, nfarR, nrmR, nrvR, nserR, noccL, nfarL, nrmL, nrvL, nserL;
+            int noccR, nfarR, nrmR, nserR, noccL, nfarL, nrmL, nserL;
             int ragR, ragL;
-            int b = zone_near(+1, tL, fvR, noccR, nfarR, nrmR, ragR, nrvR, nserR);
+            FargVec farg;               // per test site: minus the log of the factor its product picks up from the far fields (exp_neg's argument)
+#pragma unroll
+            for (int j = 0; j < J; ++j) farg[j] = 0.0;
+            int b = zone_near(std::integral_constant<int, +1>{}, tL, fvR, noccR, nfarR, nrmR, ragR, nserR, farg);
             if (b != PREP_ZONE_DONE) { while (!generic_pass(b, +1, N, false)) b += SP; }
             PROF_MARK(4);
-            b = zone_near(-1, t0, fvL, noccL, nfarL, nrmL, ragL, nrvL, nserL);
+            b = zone_near(std::integral_constant<int, -1>{}, t0, fvL, noccL, nfarL, nrmL, ragL, nserL, farg);
             if (b != PREP_ZONE_DONE) { while (!generic_pass(b, -1, -1, false)) b -= SP; }
             PROF_MARK(4);
             // the far fields of both zones: ONE exp per test site -- test sites in pairs, two interleaved exp chains, each pair
             // final before the next one starts
             if (!bad && (nfarR || ragR || nfarL || ragL)) {
-                double farg[J];
-#pragma unroll
-                for (int j = 0; j < J; ++j) farg[j] = 0.0;
                 auto apply_far = [&]() {
 #pragma unroll
                     for (int w = 0; w < J; w += 2) {
@@ -2409,12 +2404,12 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 const int bitsR = 2 + (int)((float)(nfarR + nrmR) * P.far_bits), bitsL = 2 + (int)((float)(nfarL + nrmL) * P.far_bits);
                 // (one copy of each zone's code: this kernel's per-A path is about as large as the instruction cache)
                 const bool split = bitsR + bitsL > 900;
-                zone_far(std::integral_constant<int, +1>{}, fvR, noccR, nserR, nfarR, nrmR, ragR, nrvR, farg);
+                zone_far(fvR, noccR, nserR, nfarR, farg);
                 if (split) {
                     spend(bitsR);
                     apply_far();
                 }
-                zone_far(std::integral_constant<int, -1>{}, fvL, noccL, nserL, nfarL, nrmL, ragL, nrvL, farg);
+                zone_far(fvL, noccL, nserL, nfarL, farg);
                 spend(split ? bitsL : bitsR + bitsL);
                 apply_far();
             }
@@ -2424,7 +2419,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
             for (int j = 0; j < J; ++j) {
                 const int ec = min(max(E[j], -131071), 131071) + 131072;
                 const int eb = bestK[j] >> 13;
-                const bool better = (ec > eb) || (ec == eb && acc[j] > bestM[j]);
+                const bool better = ((ec > eb) || (ec == eb && acc[j] > bestM[j])) && (!BMX_FREXP || acc[j] > 0.0);
                 if (better && p < P.npairs) {
                     bestM[j] = acc[j];
                     bestK[j] = (ec << 13) | iA;
@@ -2464,18 +2459,30 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
 // ----------------------------------------------------------------------------- K2, prepared, one test site per wave
 // Sparse test sets (the reference's -s with a large step), unsorted test positions: windows share too little for groups.
 // The same split as above with J = 1: prep_solo_kernel walks each test site's window once per A -- both sides; with one
-// test site the decay separates trivially (alpha_i = E_i, F = 1), so the two sides share ONE near list and ONE set of
-// moments -- and clr_scan_solo_kernel, one wave per (test site, slice), multiplies the near list four sites per step, folds the
-// moments and takes one exp per A.  The round-2 per-site kernel did the walk (loads, exp, window test) in all eight slice
-// waves and multiplied every site of the window.
-//   blob(test site) = for iA: header (1 unit) {magic, n_near (multiple of 4), n_occ, n_far}; n_near entries (E, row offset);
-//                     4 guard entries; n_occ moment entries of 5 units: (c_1, row offset) (c_2, c_3) ... with c_k = -+ w_k M_k, the
-//                     series' coefficient already in (with F = 1 the far field of a row is one polynomial in R)
+// test site the decay separates trivially (alpha_i = E_i, F = 1), so the two sides share the near lists and ONE set of
+// moments -- and clr_scan_solo_kernel, one wave per (test site, slice), multiplies the near lists, folds the moments and takes
+// one exp per A.  The round-2 per-site kernel did the walk (loads, exp, window test) in all eight slice waves and multiplied
+// every site of the window.
+//
+// Round 3 read every entry back from the LDS ring with a broadcast ds_read_b128 next to the ds_read_b64 of its R: 9 LDS clocks per
+// entry for each of 16 waves per CU -- the LDS pipe, not the vector unit, was the bound (8.7 cycles per VALU instruction).  Round 4:
+// the sites of the most frequent row (substitutions: 70 % of the sites) need no R read at all -- that row's R sits in a register and
+// their entries are the 8-byte E alone, two per broadcast read: 0.5 LDS instructions per entry instead of 2 -- and the slices of a
+// chunk of test sites run on one XCD, so that a stream comes out of HBM once, not eight times.
+// (Measured and dropped in round 4: the whole stream through the scalar cache -- s_load_dwordx16 from the constant address space,
+// entries as scalar operands, no ring at all: 0.80 M windows/s against round 3's 1.35 M.  A wave gets one 64-byte line per ~2200
+// cycles that way: the scalar cache is built for a few hot constants, not for 88 KB of stream per wave.)
+//   blob(test site) = for iA:  one or more SEGMENTS, then the far field
+//     segment   = header, 64 B: {magic | last, n0, n1, n_occ} {n_far, 0, 0, 0} ...
+//                 n0 (a multiple of 8) entries of the most frequent row: E (8 B each)
+//                 n1 (a multiple of 4) entries of the other rows: (E, row offset, 0) (16 B each); all 64-byte aligned;
+//                 lists padded with neutral entries (E = 0); a segment is flushed from prep_solo_kernel's LDS staging lists
+//                 whenever they fill, so any window size goes through fixed-size staging
+//     far field = n_occ moment entries of 5 units: (c_1 .. c_8) (row offset), c_k = -+ w_k M_k, the series' coefficient already
+//                 in (with F = 1 the far field of a row is one polynomial in R); padded to a multiple of 4 units
 constexpr int SOLO_MAGIC = 0x50100000;
-constexpr int SOLO_GUARD = 4;
-// Far field of the solo kernels: order 8 on |x| <= 0.05 (the round-2 series).  With one test site per wave the fold of the moments
-// (order x occupied rows per A, nothing to share it among) weighs as much as the near list, and order 12 measured slower here
-// (1.27 -> 1.14 M windows/s at stride 64) while it is faster for groups of 16.  The per-row thresholds on the device are
+constexpr int SOLO_S0 = 256, SOLO_S1 = 192;        // staging lists per wave: E of the most frequent row / (E, row offset) of the others
+// Far field of the solo kernels: order 8 on |x| <= 0.05 (the round-2 series).  The per-row thresholds on the device are
 // those of the grouped kernels (P_EPS): a site is far here S_SHIFT = log(P_EPS / S_EPS) later.
 constexpr int S_ORDER = 8, S_COPIES = 8, S_MOM = 1 + S_ORDER / 2, S_FAR_CAP = 8192;
 // (S_EPS = 0.05)
@@ -2498,6 +2505,9 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
     }
     const int mom_len = (P.mom_slots + S_COPIES - 1 + 3) * S_ORDER;
     double *mom = lds_p + thr_len + wave * mom_len;
+    // staging lists of the near entries (fill pass): the most frequent row's E, then the other rows' (E, row offset)
+    double *st0 = lds_p + thr_len + nw * mom_len + wave * (SOLO_S0 + 2 * SOLO_S1);
+    ScratchEnt *st1 = reinterpret_cast<ScratchEnt *>(st0 + SOLO_S0);
     for (int idx = lane; idx < mom_len; idx += WAVE) mom[idx] = 0.0;
     __builtin_amdgcn_wave_barrier();
     const int64_t t = P.g_begin + (int64_t)blockIdx.x * nw + wave;       // "group" = one test site
@@ -2514,6 +2524,7 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
     const int lo = (int)max(P.win_lo[t], (int64_t)0);
     const int hi = (int)min(P.win_hi[t], (int64_t)N - 1);
     const int c = (int)P.center[t], ch = (int)P.center_hi[t];     // sites in [c, ch) sit AT the test position: never in its window (v1:455)
+    const int row0 = P.row_of_slot[0];                            // the most frequent row of the data (its R stays in a register of the consumer)
     int wpos = 0;
     ScratchEnt *out = nullptr;
     if (FILL) out = P.arena + (P.blob_prefix[t] - P.prefix_base);
@@ -2521,10 +2532,32 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
     for (int iA = 0; iA < P.nA; ++iA) {
         const double A = P.A[iA];
         const int kmom = min((int)P.kmom[iA], P.mom_slots);
-        const int hbase = wpos, nbase = hbase + 1;
-        int n_near = 0, nfar_tot = 0, pad_ro = 0;
+        int n0 = 0, n1 = 0, nfar_tot = 0, pad_ro = 0;       // n0 / n1: entries staged for the next segment
         bool seen = false;
         double m1p = 0.0, m2p = 0.0;
+        // one segment of the stream from the staging lists: header, the E of the most frequent row (padded to 8), the other rows'
+        // entries (padded to 4)
+        auto flush = [&](bool last, int n_occ) {
+            const int n0p = (n0 + 7) & ~7, n1p = (n1 + 3) & ~3;
+            if (FILL) {
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    int4 *h = reinterpret_cast<int4 *>(out + wpos);
+                    h[0] = int4{SOLO_MAGIC | (last ? 1 : 0), n0p, n1p, n_occ};
+                    h[1] = int4{nfar_tot, 0, 0, 0};
+                    h[2] = int4{0, 0, 0, 0};
+                    h[3] = int4{0, 0, 0, 0};
+                }
+                double *o0 = reinterpret_cast<double *>(out + wpos + 4);
+                for (int i = lane; i < n0p; i += WAVE) o0[i] = i < n0 ? st0[i] : 0.0;
+                ScratchEnt *o1 = out + wpos + 4 + n0p / 2;
+                for (int i = lane; i < n1p; i += WAVE) o1[i] = i < n1 ? st1[i] : ScratchEnt{0.0, pad_ro, 0};
+                __builtin_amdgcn_wave_barrier();
+            }
+            wpos += 4 + n0p / 2 + n1p;
+            n0 = 0;
+            n1 = 0;
+        };
         for (int dir = 0; dir < 2; ++dir) {
             // dir 0: indices max(ch, lo), +1, ... up to hi;  dir 1: min(c - 1, hi), -1, ... down to lo
             const int base = dir == 0 ? max(ch, lo) : min(c - 1, hi);
@@ -2547,7 +2580,8 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
                     const double th = th0 + S_SHIFT;                    // (NaN stays NaN: rows absent from the helper file are never far)
                     const bool moml = in && slot < kmom && zn >= th && nfar_tot < S_FAR_CAP;
                     const bool nearl = in && !moml;
-                    const unsigned long long mm = __ballot(moml), mn = __ballot(nearl);
+                    const bool near0 = nearl && rraw == row0;
+                    const unsigned long long mm = __ballot(moml), mn0 = __ballot(near0), mn1 = __ballot(nearl && !near0);
                     const int nfar = __popcll(mm);
                     if (!seen) { pad_ro = __builtin_amdgcn_readlane(rraw, __ffsll((long long)m_in) - 1) * P.rowmul; seen = true; }
                     double Ev = 0.0;
@@ -2573,85 +2607,96 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
                         }
                         nfar_tot += nfar;
                     }
-                    if (FILL && nearl) out[nbase + n_near + rank(mn)] = ScratchEnt{Ev, rraw * P.rowmul, 0};
-                    n_near += __popcll(mn);
+                    // a pass adds at most 64 entries to either list: a segment goes out before one could overflow
+                    if (n0 + WAVE > SOLO_S0 || n1 + WAVE > SOLO_S1) flush(false, 0);
+                    if (FILL) {
+                        if (near0) st0[n0 + rank(mn0)] = Ev;
+                        if (nearl && !near0) st1[n1 + rank(mn1)] = ScratchEnt{Ev, rraw * P.rowmul, 0};
+                    }
+                    n0 += __popcll(mn0);
+                    n1 += __popcll(mn1);
                 }
                 // the walk ends where the window does: its index bound, or the first site past the cut-off (positions are sorted)
                 if (__ballot(valid && zn > P.zcut) != 0ull || __ballot(valid) != ~0ull) break;
                 i = inx;
             }
         }
-        const int n_near_pad = (n_near + 3) & ~3;
-        if (FILL) {
-            if (lane < n_near_pad - n_near + SOLO_GUARD) out[nbase + n_near + lane] = ScratchEnt{0.0, pad_ro, 0};
-        }
-        wpos = nbase + n_near_pad + SOLO_GUARD;
+        // the moments of the occupied slots, premultiplied by the series' coefficients; they follow the last segment
         int n_occ = 0;
+        bool occ0 = false;
+        double x0 = 0.0;
         if (nfar_tot) {
             __builtin_amdgcn_wave_barrier();
-            {
-                double x = 0.0;
-                if (lane < S_COPIES * S_ORDER) {
-                    x = mom[lane];
-                    mom[lane] = 0.0;
+            if (lane < S_COPIES * S_ORDER) {
+                x0 = mom[lane];
+                mom[lane] = 0.0;
+            }
+            if (FILL) {
+                double y1 = m1p, y2 = m2p;
+#pragma unroll
+                for (int off = 1; off < WAVE; off <<= 1) {
+                    y1 += __shfl_xor(y1, off);
+                    y2 += __shfl_xor(y2, off);
                 }
+                x0 += lane == 0 ? y1 : lane == 1 ? y2 : 0.0;
+            }
+#pragma unroll
+            for (int cc = S_COPIES / 2; cc >= 1; cc >>= 1) x0 += __shfl_down(x0, cc * S_ORDER);
+            occ0 = readlane_f64(x0, 0) != 0.0;
+            n_occ = occ0 ? 1 : 0;
+            // count the other occupied slots first: the last segment's header carries n_occ
+            for (int s0 = 1; s0 < kmom; s0 += WAVE) {
+                const int sl = s0 + lane;
+                const bool occ = sl < kmom && mom[(sl + S_COPIES - 1) * S_ORDER] != 0.0;
+                n_occ += __popcll(__ballot(occ));
+            }
+        }
+        flush(true, n_occ);
+        if (nfar_tot) {
+            int at = 0;
+            if (occ0) {
                 if (FILL) {
-                    double y1 = m1p, y2 = m2p;
+                    double m[S_ORDER];
 #pragma unroll
-                    for (int off = 1; off < WAVE; off <<= 1) {
-                        y1 += __shfl_xor(y1, off);
-                        y2 += __shfl_xor(y2, off);
+                    for (int k = 0; k < S_ORDER; ++k) m[k] = readlane_f64(x0, k) * ((k & 1) ? -S_W[k] : S_W[k]);     // c_k = -+ w_k M_k
+                    if (lane == 0) {
+                        double2 *o2 = reinterpret_cast<double2 *>(out + wpos);
+#pragma unroll
+                        for (int q = 0; q < S_ORDER / 2; ++q) o2[q] = double2{m[2 * q], m[2 * q + 1]};
+                        *reinterpret_cast<int4 *>(out + wpos + S_ORDER / 2) = int4{row0 * P.rowmul, 0, 0, 0};
                     }
-                    x += lane == 0 ? y1 : lane == 1 ? y2 : 0.0;
                 }
-#pragma unroll
-                for (int cc = S_COPIES / 2; cc >= 1; cc >>= 1) x += __shfl_down(x, cc * S_ORDER);
-                const double m0 = readlane_f64(x, 0);
-                if (m0 != 0.0) {
-                    if (FILL) {
-                        double m[S_ORDER];
-#pragma unroll
-                        for (int k = 0; k < S_ORDER; ++k) m[k] = readlane_f64(x, k) * ((k & 1) ? -S_W[k] : S_W[k]);     // c_k = -+ w_k M_k
-                        if (lane == 0) {
-                            ScratchEnt *o = out + wpos;
-                            o[0] = ScratchEnt{m[0], P.row_of_slot[0] * P.rowmul, 0};
-                            double2 *o2 = reinterpret_cast<double2 *>(o + 1);
-#pragma unroll
-                            for (int q = 0; q < S_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < S_ORDER ? m[2 * q + 2] : 0.0};
-                        }
-                    }
-                    n_occ = 1;
-                }
+                at = 1;
             }
             for (int s0 = 1; s0 < kmom; s0 += WAVE) {
-                const int s = s0 + lane;
+                const int sl = s0 + lane;
                 double m[S_ORDER];
 #pragma unroll
                 for (int k = 0; k < S_ORDER; ++k) m[k] = 0.0;
-                if (s < kmom) {
-                    double *ms = mom + (s + S_COPIES - 1) * S_ORDER;
+                if (sl < kmom) {
+                    double *ms = mom + (sl + S_COPIES - 1) * S_ORDER;
 #pragma unroll
                     for (int k = 0; k < S_ORDER; ++k) { m[k] = ms[k]; ms[k] = 0.0; }
                 }
                 const bool occ = m[0] != 0.0;
                 const unsigned long long mo = __ballot(occ);
-                if (FILL) {
+                if (FILL && occ) {
 #pragma unroll
                     for (int k = 0; k < S_ORDER; ++k) m[k] *= (k & 1) ? -S_W[k] : S_W[k];
-                }
-                if (FILL && occ) {
-                    ScratchEnt *o = out + wpos + S_MOM * (n_occ + rank(mo));
-                    o[0] = ScratchEnt{m[0], P.row_of_slot[s] * P.rowmul, 0};
-                    double2 *o2 = reinterpret_cast<double2 *>(o + 1);
+                    ScratchEnt *o = out + wpos + S_MOM * (at + rank(mo));
+                    double2 *o2 = reinterpret_cast<double2 *>(o);
 #pragma unroll
-                    for (int q = 0; q < S_ORDER / 2; ++q) o2[q] = double2{m[2 * q + 1], 2 * q + 2 < S_ORDER ? m[2 * q + 2] : 0.0};
+                    for (int q = 0; q < S_ORDER / 2; ++q) o2[q] = double2{m[2 * q], m[2 * q + 1]};
+                    *reinterpret_cast<int4 *>(o + S_ORDER / 2) = int4{P.row_of_slot[sl] * P.rowmul, 0, 0, 0};
                 }
-                n_occ += __popcll(mo);
+                at += __popcll(mo);
             }
             __builtin_amdgcn_wave_barrier();
-            wpos += S_MOM * n_occ;
+            // (at == n_occ: both loops apply the same test to the same LDS values)
+            const int far_units = (S_MOM * n_occ + 3) & ~3;            // the next header on a 64-byte boundary
+            if (FILL && lane < far_units - S_MOM * n_occ) out[wpos + S_MOM * n_occ + lane] = ScratchEnt{0.0, 0, 0};
+            wpos += far_units;
         }
-        if (FILL && lane == 0) *reinterpret_cast<int4 *>(out + hbase) = int4{SOLO_MAGIC, n_near_pad, n_occ, nfar_tot};
     }
     const int units = (wpos + 3) & ~3;
     if (!FILL) {
@@ -2668,8 +2713,8 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_solo_kernel(ScanParams 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = blockDim.x / WAVE;
 #if BMX_SOLO_XCD_MAP
-    // the slices of one chunk of test sites on one XCD, next to each other in its dispatch order (see the prepared kernel): the
-    // blobs are 100 KB per test site here and every slice reads all of them
+    // the slices of one chunk of test sites on one XCD, next to each other in its dispatch order (see the prepared kernel): every
+    // slice reads all of the chunk's streams, and with this placement seven of the eight reads hit that XCD's L2
     const int xcd = blockIdx.x & 7;
     const int64_t q = blockIdx.x >> 3;
     const int slice = (int)(q % P.nslices);
@@ -2694,12 +2739,15 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_solo_kernel(ScanParams 
     double2 *ring2 = reinterpret_cast<double2 *>(ring);
     for (int idx = lane; idx < WAVE_UNITS; idx += WAVE) ring[idx] = ScratchEnt{0.0, 0, 0};
     if (USE_LDS) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    const int rowmul = USE_LDS ? WAVE : P.NP;
+    const double R0 = P.row0 >= 0 ? loadR(P.row0 * rowmul) : 0.0;       // the most frequent row of the data: its entries carry no row offset
+    // every factor 1 + E R lies within 2^-54 .. 2^span_hi (or is exactly 0): P.renorm_every of them between two exponent extractions
+    const int lim = P.renorm_every;
 
     const int64_t t_begin = chunk * P.sites_per_block;
     const int64_t t_end = min(t_begin + (int64_t)P.sites_per_block, P.M);
     for (int64_t t = t_begin + wave; t < t_end; t += nw) {
-        // the stream of this test site through the ring, as in the prepared kernel (two chunks in flight and the slices of a
-        // chunk of test sites on one XCD were both measured here: 1.27 -> 1.21 M windows/s and no change)
+        // the stream of this test site through the ring, as in the prepared kernel
         const double2 *src = reinterpret_cast<const double2 *>(V.arena + (V.blob_prefix[V.grp_base + t] - V.prefix_base));
         int pos = 0, staged_u = 0;
         double nx_a, nx_b;
@@ -2722,35 +2770,57 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_solo_kernel(ScanParams 
         stage();
         stage();
         bool bad = false;
-        double bestM = 1.0;
-        int bestEc = 131072, bestA = -1;
+        double bestM = 0.5;                         // the product 1 = 0.5 * 2^1 in renorm_fx's convention: only a larger one wins (v1:451,501)
+        int bestEc = 131072 + 1, bestA = -1;
         for (int iA = 0; iA < P.nA && !bad; ++iA) {
-            need();
-            const int4 h = *reinterpret_cast<const int4 *>(ring + (pos & (RING_UNITS - 1)));
-            const int magic = __builtin_amdgcn_readfirstlane(h.x), n_near = __builtin_amdgcn_readfirstlane(h.y);
-            const int n_occ = __builtin_amdgcn_readfirstlane(h.z), nfar = __builtin_amdgcn_readfirstlane(h.w);
-            if (magic != SOLO_MAGIC || n_near < 0 || (n_near & 3) || n_near > (int)P.N + 8 || n_occ < 0 || n_occ > MOM_SLOTS) { bad = true; break; }
-            pos += 1;
             double acc = 1.0;
             int E = 0, since = 0;
-            for (int l = 0; l < n_near; l += 4) {
+            int n_occ = 0, nfar = 0;
+            for (;;) {
                 need();
-                const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
-                double f[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const ScratchEnt en = rp[u];                    // uniform address: LDS broadcast
-                    f[u] = fma(en.e, loadR(en.ro), 1.0);
-                }
-                acc *= (f[0] * f[1]) * (f[2] * f[3]);
-                since += 4;
-                if (since + 4 > P.renorm_every) {
-                    renorm(acc, E);
-                    since = 0;
+                const int4 *hp = reinterpret_cast<const int4 *>(ring + (pos & (RING_UNITS - 1)));
+                const int4 h0 = hp[0], h1 = hp[1];
+                const int magic = __builtin_amdgcn_readfirstlane(h0.x), n0 = __builtin_amdgcn_readfirstlane(h0.y);
+                const int n1 = __builtin_amdgcn_readfirstlane(h0.z), nocc = __builtin_amdgcn_readfirstlane(h0.w);
+                if ((magic & ~1) != SOLO_MAGIC || n0 < 0 || (n0 & 7) || n1 < 0 || (n1 & 3) || n0 > (int)P.N + 8 || n1 > (int)P.N + 8 || nocc < 0 || nocc > MOM_SLOTS) {
+                    bad = true;
+                    break;
                 }
                 pos += 4;
+                // the most frequent row: two E per broadcast read, R in a register, eight entries per step
+                for (int b = 0; b < n0; b += 8) {
+                    need();
+                    const double2 *ep = reinterpret_cast<const double2 *>(ring + (pos & (RING_UNITS - 1)));
+                    double f[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double2 e = ep[k];                       // uniform address: LDS broadcast
+                        f[2 * k] = fma(e.x, R0, 1.0);
+                        f[2 * k + 1] = fma(e.y, R0, 1.0);
+                    }
+                    if (since + 8 > lim) { renorm_fx(acc, E); since = 0; }
+                    acc *= ((f[0] * f[1]) * (f[2] * f[3])) * ((f[4] * f[5]) * (f[6] * f[7]));
+                    since += 8;
+                    pos += 4;
+                }
+                // the other rows: (E, row offset) per broadcast read, R from the LDS slice (or L2), four entries per step
+                for (int b = 0; b < n1; b += 4) {
+                    need();
+                    const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
+                    double f[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const ScratchEnt en = rp[k];
+                        f[k] = fma(en.e, loadR(en.ro), 1.0);
+                    }
+                    if (since + 4 > lim) { renorm_fx(acc, E); since = 0; }
+                    acc *= (f[0] * f[1]) * (f[2] * f[3]);
+                    since += 4;
+                    pos += 4;
+                }
+                if (magic & 1) { n_occ = nocc; nfar = __builtin_amdgcn_readfirstlane(h1.x); break; }
             }
-            pos += SOLO_GUARD;
+            if (bad) break;
             if (nfar) {
                 // With F = 1 the series collapses per row: log factor = sum_rows sum_k c_k R^k, c_k = -+ w_k M_k premultiplied by the
                 // preparation kernel -- one Horner chain in R per occupied row (both sides of the window at once)
@@ -2758,26 +2828,26 @@ __global__ __launch_bounds__(SITE_THREADS) void clr_scan_solo_kernel(ScanParams 
                 for (int s = 0; s < n_occ; ++s) {
                     need();
                     const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
-                    const ScratchEnt ua = rp[0];
-                    const double R = loadR(ua.ro);
-                    const double2 *qa = reinterpret_cast<const double2 *>(rp + 1);
-                    double h = 0.0;
+                    const double2 *qa = reinterpret_cast<const double2 *>(rp);
+                    const int ro = reinterpret_cast<const int *>(rp + S_ORDER / 2)[0];
+                    const double R = loadR(ro);
+                    double hh = 0.0;
 #pragma unroll
-                    for (int k = S_ORDER; k >= 2; --k) {
-                        const double2 v = qa[(k - 2) >> 1];
-                        h = fma(h, R, (k & 1) ? v.y : v.x);
+                    for (int k = S_ORDER - 1; k >= 0; --k) {
+                        const double2 v = qa[k >> 1];
+                        hh = fma(hh, R, (k & 1) ? v.y : v.x);
                     }
-                    h = fma(h, R, ua.e);
-                    tsum = fma(h, R, tsum);
+                    tsum = fma(hh, R, tsum);
                     pos += S_MOM;
                 }
-                renorm(acc, E);                      // |tsum| <= S_FAR_CAP * S_EPS * 1.1 < 600: 2^860 on top of [1, 2) is safe
+                pos = (pos + 3) & ~3;
+                renorm_fx(acc, E);                   // |tsum| <= S_FAR_CAP * S_EPS * 1.1 < 600: 2^860 on top of [1/2, 1) is safe
                 since = 0;
                 acc *= exp_neg(-tsum);
             }
-            renorm(acc, E);
+            renorm_fx(acc, E);
             const int ec = min(max(E, -131071), 131071) + 131072;
-            if (((ec > bestEc) || (ec == bestEc && acc > bestM)) && p < P.npairs) {       // strict '>' (v1:501); iA ascending
+            if (((ec > bestEc) || (ec == bestEc && acc > bestM)) && acc > 0.0 && p < P.npairs) {       // strict '>' (v1:501); iA ascending
                 bestM = acc;
                 bestEc = ec;
                 bestA = iA;
@@ -2832,7 +2902,12 @@ __global__ void finalize_kernel(FinalParams F) {
             bL = L;
         }
     }
-    if (bL != 0x7fffffff) bT = 2.0 * ((double)(bE - 131072) * LN2 + log(bM));
+    if (bL != 0x7fffffff) {
+        // kernels that normalise with v_frexp hand over mantissas in [1/2, 1): back to [1, 2), or a product just above 1 would come
+        // out as LN2 + log(0.5000...) -- a difference of two numbers of size 0.69
+        if (bM < 1.0) { bM *= 2.0; bE -= 1; }
+        bT = 2.0 * ((double)(bE - 131072) * LN2 + log(bM));
+    }
     const bool none = (bL == 0x7fffffff);
     if (!none) {
         const double A = F.A[bL / F.npairs], tg = F.test_gen[t];
@@ -3559,6 +3634,10 @@ int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64
 
 namespace {
 
+// the dynamic-LDS limit of a kernel is set per FUNCTION and launches read it: attribute + launch pairs of different contexts
+// (threads of bmx_scan_multi, a caller's own threads) must not interleave
+std::mutex g_launch_mu;
+
 int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
     ScanParams &P = pl.P;
     P.genpos = s->genpos.p; P.row = RowArray{s->wide_rows ? nullptr : s->row16.p, s->wide_rows ? s->row32.p : nullptr}; P.N = s->N; P.Rt = c->d_Rt;
@@ -3691,8 +3770,9 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
         const size_t mom_count = solo ? mom_fill : 2 * (size_t)(pm + P_COPIES - 1 + 3) + WAVE;      // grouped counting pass: one flag per slot
         pl.prep_threads = mom_fill * sizeof(double) > 20480 ? PREP_THREADS / 4 : PREP_THREADS;          // (all 254 slots: 25 KB per moment array)
         const size_t thr_b = pl.thr_in_lds ? (size_t)((c->rows + 1) & ~1) * sizeof(double) : 0;
-        pl.prep_lds = thr_b + (size_t)(pl.prep_threads / WAVE) * (mom_fill * sizeof(double) + (solo ? 0 : 2 * SER_CAP * sizeof(ScratchEnt)));
-        pl.prep_lds_count = thr_b + (size_t)(pl.prep_threads / WAVE) * mom_count * sizeof(double);
+        const size_t stage_b = solo ? (size_t)(SOLO_S0 + 2 * SOLO_S1) * sizeof(double) : 2 * SER_CAP * sizeof(ScratchEnt);   // near-entry staging / series entries
+        pl.prep_lds = thr_b + (size_t)(pl.prep_threads / WAVE) * (mom_fill * sizeof(double) + stage_b);
+        pl.prep_lds_count = thr_b + (size_t)(pl.prep_threads / WAVE) * (mom_count * sizeof(double) + (solo ? stage_b : 0));
         P.far_bits = (float)(P_EPS * 1.4427 * 1.1);          // |log1p(x)| <= 1.09 |x| for |x| <= 0.15 (1.16 at 0.25: order 16 uses 1.2)
         if (P_ORDER == 16) P.far_bits = (float)(P_EPS * 1.4427 * 1.2);
 #define PP(JJ, FF) (const void *)prep_kernel<JJ, FF>
@@ -3744,7 +3824,11 @@ int ensure_prep(bmx_ctx *c, ChromSlot *s) {
     Q.g_begin = 0; Q.g_end = ngroups;
     const int gpw = pl.prep_threads / WAVE;
     void *kargs[] = {&Q};
-    HIP_TRY(hipLaunchKernel(pl.prep_count, dim3((unsigned)((ngroups + gpw - 1) / gpw)), dim3(pl.prep_threads), kargs, pl.prep_lds_count, c->stream));
+    {
+        std::lock_guard<std::mutex> launch_lock(g_launch_mu);
+        if (pl.prep_lds_count) HIP_TRY(hipFuncSetAttribute(pl.prep_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prep_lds_count));
+        HIP_TRY(hipLaunchKernel(pl.prep_count, dim3((unsigned)((ngroups + gpw - 1) / gpw)), dim3(pl.prep_threads), kargs, pl.prep_lds_count, c->stream));
+    }
     hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, c->stream, (const int32_t *)s->blob_units.p, ngroups, s->blob_prefix.p);
     HIP_TRY(hipGetLastError());
     std::vector<int64_t> pre((size_t)ngroups + 1);
@@ -3791,6 +3875,7 @@ int ensure_plan(bmx_ctx *c, ChromSlot *s) {
 
 // scan + finalize of test sites [off, off + cnt) on the context's stream (asynchronous)
 int launch_range(bmx_ctx *c, ChromSlot *s, ScanPlan &pl, int64_t off, int64_t cnt, const PrepRange *pr) {
+    std::lock_guard<std::mutex> launch_lock(g_launch_mu);
     ScanParams P = pl.P;
     const size_t np = (size_t)cnt * c->nslices;
     HIP_TRY(c->part_T.ensure(np));
@@ -3799,6 +3884,7 @@ int launch_range(bmx_ctx *c, ChromSlot *s, ScanPlan &pl, int64_t off, int64_t cn
     P.test_gen = s->test_gen.p + off; P.win_lo = s->win_lo.p + off; P.win_hi = s->win_hi.p + off;
     P.center = s->center.p + off; P.center_hi = s->center_hi.p + off; P.M = cnt;
     P.part_T = c->part_T.p; P.part_lin = c->part_lin.p; P.part_ns = c->part_ns.p;
+    if (pl.lds_bytes) HIP_TRY(hipFuncSetAttribute(pl.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
     int64_t blocks = (cnt + pl.spb - 1) / pl.spb * c->nslices;
     if (pr && (pl.mode == 5 ? BMX_SOLO_XCD_MAP : BMX_XCD_MAP)) blocks = ((cnt + pl.spb - 1) / pl.spb + 7) / 8 * 8 * c->nslices;     // chunks padded to whole XCD rounds
     if (pr) {
@@ -3808,6 +3894,9 @@ int launch_range(bmx_ctx *c, ChromSlot *s, ScanPlan &pl, int64_t off, int64_t cn
         Q.g_begin = pr->g0; Q.g_end = pr->g0 + pr->ng; Q.prefix_base = pr->pbase;
         const int gpw = pl.prep_threads / WAVE;
         void *qargs[] = {&Q};
+        // (the dynamic-LDS limit is an attribute of the FUNCTION, shared by every slot and context; another slot's plan may have
+        // lowered it since this one was made)
+        if (pl.prep_lds) HIP_TRY(hipFuncSetAttribute(pl.prep_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.prep_lds));
         HIP_TRY(hipLaunchKernel(pl.prep_fill, dim3((unsigned)((pr->ng + gpw - 1) / gpw)), dim3(pl.prep_threads), qargs, pl.prep_lds, c->stream));
         PrepView V;
         V.arena = c->arena.p; V.blob_prefix = s->blob_prefix.p; V.prefix_base = pr->pbase; V.grp_base = pr->g0; V.status = c->d_status;
@@ -3953,6 +4042,17 @@ int bmx_ctx_pack_records(bmx_ctx *c, void *dst, int64_t cap, int32_t dst_on_devi
                                dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
         at += s->M;
     }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return check_status(c);
+}
+
+int bmx_ctx_copy_records(bmx_ctx *c, void *dst_device, int64_t cap) {
+    if (!c || !dst_device) return fail(BMX_E_INVALID, "NULL argument");
+    ChromSlot *s = c->cur;
+    if (!s->has_tests || !s->timed) return fail(BMX_E_STATE, "no scan results in the selected slot");
+    if (cap < s->M) return fail(BMX_E_INVALID, "copy_records: destination too small");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst_device, s->rec.p, (size_t)s->M * sizeof(bmx_record), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return check_status(c);
 }

@@ -137,7 +137,9 @@ class World:
                 if world.backend == 'nccl':
                     import torch
                     rec = torch.empty((len(mine), 2), dtype=torch.int64, device=torch.device('cuda', world.device_index))
-                    sel.ctx.pack_records(device_ptr=rec.data_ptr(), cap=len(mine))     # waits for the scan, device -> device
+                    # the selected slot's records only (a reused context may hold other chromosomes' results in other slots):
+                    # waits for the scan, device -> device
+                    sel.ctx.copy_records(device_ptr=rec.data_ptr(), cap=len(mine))
                 else:
                     rec = sel.ctx.fetch_records()
             else:

@@ -154,6 +154,13 @@ class Context:
         _lib.check(self._L.bmx_ctx_pack_records(self._h, rec.ctypes.data_as(C.c_void_p), len(rec), 0, C.byref(n)))
         return rec[:n.value]
 
+    def copy_records(self, device_ptr, cap):
+        """The SELECTED slot's records into a device buffer of this GPU (room for cap records); waits for the scan."""
+        if cap < self.M:
+            raise ValueError('destination holds %d records, the slot has %d' % (cap, self.M))
+        _lib.check(self._L.bmx_ctx_copy_records(self._h, C.c_void_p(int(device_ptr)), int(cap)))
+        return self.M
+
     def scan(self):
         _lib.check(self._L.bmx_ctx_scan(self._h))
 

@@ -190,6 +190,9 @@ int bmx_ctx_slot_count(bmx_ctx *c);
  * call -- to host memory (dst_on_device = 0), or to device memory of this context's GPU (1), where ONE gather then
  * moves them to the writing rank.  dst: room for `cap` records; *n_out (may be NULL): records written.  Blocks. */
 int bmx_ctx_pack_records(bmx_ctx *c, void *dst, int64_t cap, int32_t dst_on_device, int64_t *n_out);
+/* The SELECTED slot's M records to device memory of this context's GPU (room for `cap` >= M records), device to device on the
+ * context's stream; blocks until done.  What a sharded run gathers per input file when the context also holds other slots. */
+int bmx_ctx_copy_records(bmx_ctx *c, void *dst_device, int64_t cap);
 /* What the scan of the selected slot launches (valid once its test sites are set): *J = test sites per wave-group (0: one
  * test site per wave), *use_lds = 1 if the R slice is read from LDS, *mode = 4 prepared pipeline (prep_kernel +
  * clr_scan_prepared_kernel), 5 prepared pipeline with one test site per wave (prep_solo_kernel + clr_scan_solo_kernel, *J = 1:
@@ -198,8 +201,8 @@ int bmx_ctx_pack_records(bmx_ctx *c, void *dst, int64_t cap, int32_t dst_on_devi
 int bmx_ctx_plan(bmx_ctx *c, int32_t *J, int32_t *use_lds, int32_t *mode, int64_t *stream_bytes);
 /* Where the selected slot's scan is cut into launches: offs[i] = index of the first test site of launch range i (offs[0] = 0;
  * range i ends where range i + 1 begins, the last one at M).  At most `cap` entries are written; *n_out = number of ranges.
- * A window's result must not depend on the cut -- the parity tests compare the windows on either side of every cut
- * with the oracle.  Valid once the test sites are set. */
+ * A window's result must not depend on the cut -- the parity tests recompute the windows on either side of every cut
+ * independently.  Valid once the test sites are set. */
 int bmx_ctx_launch_ranges(bmx_ctx *c, int64_t *offs, int32_t cap, int32_t *n_out);
 
 /* ---- input ingest (host only) ------------------------------ */

@@ -8,6 +8,7 @@
 template <int MODE>
 __global__ __launch_bounds__(256) void k(double *out, const double *in, int iters) {
     double acc[8];
+    int ex[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const double c1 = in[0], c2 = in[1];          // uniform -> SGPR
     const double f0 = in[2], f1 = in[3], f2 = in[4], f3 = in[5], f4 = in[6], f5 = in[7], f6 = in[8], f7 = in[9];
     double s = in[10] + threadIdx.x * 1e-9, q = in[11] + threadIdx.x * 1e-9;
@@ -30,6 +31,23 @@ __global__ __launch_bounds__(256) void k(double *out, const double *in, int iter
             acc[6] *= fma(f6, fma(f6, q, s), 1.0);
             acc[7] *= fma(f7, fma(f7, q, s), 1.0);
             s += 1e-12; q -= 1e-12;   // 2 more DP ops, keeps the compiler from hoisting
+        } else if (MODE == 4) {   // exponent extraction as the scan kernels did it up to round 3: integer ops on the high word
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] *= c1;
+                unsigned hi = (unsigned)__double2hiint(acc[j]);
+                int e = (int)((hi >> 20) & 0x7ffu);
+                ex[j] = (e == 0) ? -(1 << 28) : ex[j] + (e - 1023);
+                hi = (hi & 0x800fffffu) | 0x3ff00000u;
+                acc[j] = __hiloint2double((int)hi, __double2loint(acc[j]));
+            }
+        } else if (MODE == 5) {   // ... with v_frexp_exp_i32_f64 / v_frexp_mant_f64
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] *= c1;
+                ex[j] += __builtin_amdgcn_frexp_exp(acc[j]);
+                acc[j] = __builtin_amdgcn_frexp_mant(acc[j]);
+            }
         } else if (MODE == 3) {   // FP32 FMA for reference
             float a[8];
 #pragma unroll
@@ -44,7 +62,7 @@ __global__ __launch_bounds__(256) void k(double *out, const double *in, int iter
     }
     double r = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r += acc[j];
+    for (int j = 0; j < 8; ++j) r += acc[j] + ex[j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
@@ -57,9 +75,10 @@ int main() {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 200000;
-    const double per_iter[4] = {8, 8, 26, 32};       // VALU instructions per iteration per wave
-    const char *name[4] = {"v_fma_f64 x8", "v_mul_f64 x8", "pair body (16 fma + 8 mul + 2 add)", "v_fma_f32 x32 (+cvt)"};
-    for (int mode = 0; mode < 4; ++mode)
+    const double per_iter[6] = {8, 8, 26, 32, 56, 32};       // VALU instructions per iteration per wave
+    const char *name[6] = {"v_fma_f64 x8", "v_mul_f64 x8", "pair body (16 fma + 8 mul + 2 add)", "v_fma_f32 x32 (+cvt)",
+                           "mul + integer renorm x8 (7 VALU each)", "mul + frexp renorm x8 (4 VALU each)"};
+    for (int mode = 0; mode < 6; ++mode)
         for (int blocks : {256, 512, 1024}) {       // 1, 2, 4 waves per SIMD
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipEventRecord(e0));
@@ -67,6 +86,8 @@ int main() {
                 if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, dout, din, iters);
                 if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, dout, din, iters);
                 if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, dout, din, iters);
+                if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, dout, din, iters);
+                if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, dout, din, iters);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
             }

@@ -11,6 +11,7 @@ outputs) next to this script.
     python tests/golden/make_golden.py setorder   # list(set(grid)) iteration orders
     python tests/golden/make_golden.py surface    # per-site T[A,x,a] surfaces
     python tests/golden/make_golden.py helpers    # --getSpect / --getConfig outputs
+    python tests/golden/make_golden.py hostmodel  # NeutralSFS / InputData state after construction (bitwise) + stdout
     python tests/golden/make_golden.py e2e NAME   # whole-CLI runs (slow, minutes..)
     python tests/golden/make_golden.py synth      # synthetic 20k / 1M strided windows
     python tests/golden/make_golden.py config4 21 22   # BASELINE config 4: chromosomes of the 40M-SNP genome, -s 50000
@@ -331,8 +332,50 @@ def cmd_config5(contigs, step=125000):
                                os.path.join(outdir, 'config5_contig%d_step%d.tsv' % (c, step)))
 
 
+# ----------------------------------------------------------------------------- neutral model + input classes
+NEUTRAL_CASES = [('HC_CEU_Neut_DAF_spect_for_B2.txt', (False, False, False)), ('HC_CEU_Neut_MAF_spect_for_B2maf.txt', (False, True, False)),
+                 ('HC_CEU_Neut_DAF_spect_for_B2.txt', (False, True, False)),          # a polarised spectrum used folded (v1:195-203)
+                 ('HC_CEU_Neut_MAF-noSub_spect_for_B0maf.txt', (False, True, True)), ('HC_CEU_Neut_DAF-nosub_spect_for_B0.txt', (False, False, True)),
+                 ('HC_CEU_Neut_config_for_B1.txt', (True, False, False))]
+INPUT_CASES = [('Example1_fullSweep_200kya_DAF.txt', {}), ('Example1_fullSweep_200kya_DAF.txt', dict(nofreq=True)),
+               ('Example1_fullSweep_200kya_DAF.txt', dict(MAF=True)), ('Example2_balancing_10MYA_MAF_nosub.txt', dict(phys=True, Rrate=1.25e-6)),
+               ('Example2_balancing_10MYA_DAF.txt', dict(nosub=True)), ('Example2_balancing_10MYA_DAF.txt', dict(MAF=True, nosub=True))]
+
+
+def cmd_hostmodel():
+    """What the reference's NeutralSFS / InputData hold after construction (floats as repr strings: bitwise), plus stdout."""
+    import contextlib
+    import hashlib
+    import io
+    ref = load_ref()
+    out = {'neutral': [], 'input': []}
+    for fname, args in NEUTRAL_CASES:
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            n = ref.NeutralSFS(os.path.join(REF_TEST, fname), *args)
+        out['neutral'].append({'file': fname, 'args': list(args), 'stdout': buf.getvalue(),
+                               'spect': [[int(k), int(m), repr(float(v))] for (k, m), v in sorted(n.spect.items())],
+                               'sampProps': [[int(m), repr(float(v))] for m, v in sorted(n.sampProps.items())],
+                               'sampSizes': sorted(int(v) for v in n.sampSizes)})
+    for fname, kw in INPUT_CASES:
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            d = ref.InputData(os.path.join(REF_TEST, fname), kw.get('nofreq', False), kw.get('MAF', False), kw.get('nosub', False), 1,
+                              phys=kw.get('phys', False), Rrate=kw.get('Rrate', 1e-6))
+        h = lambda a, dt: hashlib.sha256(np.ascontiguousarray(np.asarray(a), dtype=dt).tobytes()).hexdigest()
+        out['input'].append({'file': fname, 'kw': kw, 'stdout': buf.getvalue(), 'numSites': int(d.numSites), 'minCount': int(d.minCount),
+                             'sampSizes': sorted(int(v) for v in d.sampSizes), 'position_sha256': h(d.position, np.int64),
+                             'genPos_sha256': h(d.genPos, np.float64), 'count_sha256': h(d.count, np.int64), 'total_sha256': h(d.total, np.int64)})
+    with open(os.path.join(HERE, 'hostmodel.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print('hostmodel.json: %d neutral, %d input cases' % (len(out['neutral']), len(out['input'])))
+
+
 if __name__ == '__main__':
     cmd = sys.argv[1]
+    if cmd == 'hostmodel':
+        cmd_hostmodel()
+        sys.exit(0)
     if cmd == 'lut':
         cmd_lut()
     elif cmd == 'setorder':

@@ -9,12 +9,16 @@ import pytest
 import cases
 from util import GOLD, REFT, load_json, read_tsv
 
-from ballermixplus_amd import helpers
+from ballermixplus_amd import _lib, helpers
 from ballermixplus_amd.hostmodel import Grids, InputData, NeutralSFS
 
 
 def _r(v):
     return [repr(x) for x in v]
+
+
+def _declined(*a, **k):
+    raise _lib.BmxError(-1, 'native reader declined (test)')
 
 
 def test_grid_lists_and_iteration_order_match_reference():
@@ -52,10 +56,10 @@ def test_rangeA_implements_the_evident_intent():
 ])
 def test_getSpect_is_byte_identical(tmp_path, out, inp, kw, monkeypatch):
     dst = tmp_path / out
-    helpers.getSpect(os.path.join(REFT, inp), str(dst), kw['MAF'], kw['nosub'])          # vectorised path
+    helpers.getSpect(os.path.join(REFT, inp), str(dst), kw['MAF'], kw['nosub'])          # columns from the native reader
     assert filecmp.cmp(str(dst), os.path.join(GOLD, 'helpers', out), shallow=False)
-    monkeypatch.setattr(helpers, '_columns', lambda f: None)                              # reference-style text loop
-    dst2 = tmp_path / ('loop_' + out)
+    monkeypatch.setattr(_lib, 'read_input', _declined)                                    # ... and from Python's converters
+    dst2 = tmp_path / ('py_' + out)
     helpers.getSpect(os.path.join(REFT, inp), str(dst2), kw['MAF'], kw['nosub'])
     assert filecmp.cmp(str(dst2), os.path.join(GOLD, 'helpers', out), shallow=False)
 
@@ -66,8 +70,8 @@ def test_getConfig_is_byte_identical(tmp_path, out, inp, monkeypatch):
     dst = tmp_path / out
     helpers.getConfig(os.path.join(REFT, inp), str(dst))
     assert filecmp.cmp(str(dst), os.path.join(GOLD, 'helpers', out), shallow=False)
-    monkeypatch.setattr(helpers, '_columns', lambda f: None)
-    dst2 = tmp_path / ('loop_' + out)
+    monkeypatch.setattr(_lib, 'read_input', _declined)
+    dst2 = tmp_path / ('py_' + out)
     helpers.getConfig(os.path.join(REFT, inp), str(dst2))
     assert filecmp.cmp(str(dst2), os.path.join(GOLD, 'helpers', out), shallow=False)
 
@@ -137,19 +141,45 @@ def test_window_bounds_of_each_mode():
     ('Example2_balancing_10MYA_MAF_nosub.txt', dict(phys=True, Rrate=1.25e-6)),
     ('Example2_balancing_10MYA_DAF.txt', dict(MAF=True)),
 ])
-def test_native_reader_equals_reference_text_loop(fname, kw):
-    """libbmxscan's mmap/strtod reader vs the reference's per-line parse."""
+def test_native_reader_equals_a_per_line_parse(fname, kw, monkeypatch):
+    """libbmxscan's mmap/strtod reader and the column-wise Python converters against a plain per-line parse
+    with the conversions the reference applies (v1:103-104, 121-124), written out here."""
+    from ballermixplus_amd import hostmodel
     path = os.path.join(REFT, fname)
-    fast = InputData(path, **kw)
-    slow = InputData.__new__(InputData)
-    slow.numSites = 0
-    pos_type = 1 - int(kw.get('phys', False))
-    p, g, c, t = slow._read(path, pos_type, kw.get('Rrate', 1e-6), kw.get('nofreq', False))
-    nat = fast._read_native(path, pos_type, kw.get('Rrate', 1e-6), kw.get('nofreq', False))
-    assert nat is not None, 'native reader unavailable'
-    assert np.array_equal(nat[0], np.array(p)) and np.array_equal(nat[1], np.array(g))
-    assert np.array_equal(nat[2], np.array(c).astype(np.int64)) and np.array_equal(nat[3], np.array(t))
-    assert nat[1].dtype == np.float64 and slow.numSites == len(nat[0])
+    pos_col = 1 - int(kw.get('phys', False))
+    with open(path) as fh:
+        lines = fh.read().splitlines()[1:]
+    want = ([], [], [], [])
+    for ln in lines:
+        c = ln.strip().split('\t')
+        want[0].append(int(float(c[0]))); want[1].append(float(c[pos_col])); want[2].append(int(c[2])); want[3].append(int(c[3]))
+    nat = hostmodel.read_columns(path, pos_col)
+    monkeypatch.setattr(_lib, 'read_input', _declined)
+    py = hostmodel.read_columns(path, pos_col)
+    for got in (nat, py):
+        assert all(np.array_equal(a, np.array(b)) for a, b in zip(got, want))
+        assert got[1].dtype == np.float64 and got[0].dtype == np.int64 and got[2].dtype == np.int64
+
+
+def test_hostmodel_state_equals_the_reference_classes(capsys):
+    """NeutralSFS and InputData after construction against what the reference's own classes hold (tests/golden/hostmodel.json, made
+    by importing the reference: make_golden.py hostmodel): spectrum, per-size proportions and arrays BITWISE, stdout identical."""
+    import hashlib
+    gold = load_json('hostmodel.json')
+    for c in gold['neutral']:
+        capsys.readouterr()
+        n = NeutralSFS(os.path.join(REFT, c['file']), *c['args'])
+        assert capsys.readouterr().out == c['stdout'], c['file']
+        assert [[k, m, repr(v)] for (k, m), v in sorted(n.spect.items())] == c['spect'], (c['file'], c['args'])
+        assert [[m, repr(v)] for m, v in sorted(n.sampProps.items())] == c['sampProps'] and sorted(n.sampSizes) == c['sampSizes']
+    h = lambda a, dt: hashlib.sha256(np.ascontiguousarray(np.asarray(a), dtype=dt).tobytes()).hexdigest()
+    for c in gold['input']:
+        capsys.readouterr()
+        d = InputData(os.path.join(REFT, c['file']), **c['kw'])
+        assert capsys.readouterr().out == c['stdout'], c['file']
+        assert (d.numSites, d.minCount, sorted(d.sampSizes)) == (c['numSites'], c['minCount'], c['sampSizes']), (c['file'], c['kw'])
+        assert h(d.position, np.int64) == c['position_sha256'] and h(d.genPos, np.float64) == c['genPos_sha256']
+        assert h(d.count, np.int64) == c['count_sha256'] and h(d.total, np.int64) == c['total_sha256']
 
 
 def test_native_reader_edge_cases(tmp_path):
