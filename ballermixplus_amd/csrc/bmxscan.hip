@@ -1799,6 +1799,51 @@ __global__ __launch_bounds__(1024) void prefix_kernel(const int32_t *u, int64_t 
     if (t == 1023) pre[n] = part[1023];
 }
 
+// The ragged end's walk from entry l up to (not including) nj, as ONE asm statement: entry l comes out of the registers that hold the
+// zone's ragged entries lanes-over-entries (v_readlane), its R was requested ahead (three registers, rotated), and its first three
+// Taylor terms go into the zone's power sums p0..p2.  The same instructions the compiler made of the C++ loop -- but as a statement
+// without control flow it no longer puts sixteen copies of a loop into the unrolled loop over the test sites, which is what made the
+// register allocator spill 49 registers around them (round 3).  An LDS read may still be in flight when the statement ends: the
+// caller waits for it (rag_walk_settle) before anything else may touch R2.
+__device__ __forceinline__ void rag_walk_lds(int &l, int nj, int nrmax, int e_lo, int e_hi, int ro, unsigned lds_lane_addr,
+                                             double &R0, double &R1, double &R2, double &p0, double &p1, double &p2) {
+    int tmp;
+    unsigned addr;
+    double v, v2;
+    const double third = 0.3333333333333333;
+    asm volatile(
+        "s_cmp_ge_i32 %[l], %[nj]\n\t"
+        "s_cbranch_scc1 2f\n"
+        "1:\n\t"
+        "v_readlane_b32 vcc_lo, %[elo], %[l]\n\t"
+        "v_readlane_b32 vcc_hi, %[ehi], %[l]\n\t"
+        "s_add_i32 %[tmp], %[l], 3\n\t"
+        "s_min_i32 %[tmp], %[tmp], %[nrmax]\n\t"
+        "v_readlane_b32 %[tmp], %[ro], %[tmp]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mul_f64 %[v], %[R0], vcc\n\t"
+        "v_mov_b64 %[R0], %[R1]\n\t"
+        "v_mov_b64 %[R1], %[R2]\n\t"
+        "v_lshl_add_u32 %[addr], %[tmp], 3, %[lane]\n\t"
+        "ds_read_b64 %[R2], %[addr]\n\t"
+        "v_mul_f64 %[v2], %[v], %[v]\n\t"
+        "v_add_f64 %[p0], %[p0], %[v]\n\t"
+        "v_fma_f64 %[p1], %[v2], 0.5, %[p1]\n\t"
+        "v_mul_f64 %[v2], %[v2], %[v]\n\t"
+        "v_fma_f64 %[p2], %[v2], %[third], %[p2]\n\t"
+        "s_add_i32 %[l], %[l], 1\n\t"
+        "s_cmp_lt_i32 %[l], %[nj]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        : [l] "+s"(l), [R0] "+v"(R0), [R1] "+v"(R1), [R2] "+v"(R2), [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2),
+          [tmp] "=&s"(tmp), [v] "=&v"(v), [v2] "=&v"(v2), [addr] "=&v"(addr)
+        : [nj] "s"(nj), [nrmax] "s"(nrmax), [elo] "v"(e_lo), [ehi] "v"(e_hi), [ro] "v"(ro), [lane] "v"(lds_lane_addr), [third] "s"(third)
+        : "vcc", "scc", "memory");
+}
+__device__ __forceinline__ void rag_walk_settle(double &R0, double &R1, double &R2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2) : : "memory");
+}
+
 struct PrepView {
     const ScratchEnt *arena;
     const int64_t *blob_prefix;   // the slot's exclusive prefix, indexed by absolute group
@@ -1851,6 +1896,8 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
     auto loadR = [&](int rowoff) -> double {
         return USE_LDS ? lds_R[rowoff + lane] : *reinterpret_cast<const double *>(Rb + ((unsigned)rowoff * 8u + lane8));
     };
+    // LDS byte address of this lane's column of the R slice (for the hand-written ragged-end walk)
+    const unsigned lds_lane_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)(lds_R + lane);
     double *lds_tail = lds_R + (USE_LDS ? P.rows * WAVE : 0);
     constexpr int WAVE_UNITS = RING_UNITS + RING_MIRROR + AUX_UNITS;
     ScratchEnt *ring = reinterpret_cast<ScratchEnt *>(lds_tail) + wave * WAVE_UNITS;
@@ -2159,21 +2206,34 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     const int nrag_v = nragv_o;
                     double r1 = 0.0, r2 = 0.0, r3 = 0.0;
                     int l = 0;
-#pragma nounroll
-                    for (int w = 0; w < J; ++w) {
-                        const int j = dirc > 0 ? w : J - 1 - w;
-                        const int nj = __builtin_amdgcn_readlane(nrag_v, j);
-                        for (; l < nj; ++l) {
-                            const double v = readlane_f64(ragm.e, l) * rag_R0, v2 = v * v;
-                            rag_R0 = rag_R1;
-                            rag_R1 = rag_R2;
-                            rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(l + 3, nrmax)));     // (the guard at the end)
-                            r1 += v;
-                            r2 = fma(v2, 0.5, r2);
-                            r3 = fma(v2 * v, 0.3333333333333333, r3);
+                    if (USE_LDS) {
+                        // the walk itself is one asm statement per test site (rag_walk_lds): no control flow inside the unrolled loop
+#pragma unroll
+                        for (int w = 0; w < J; ++w) {
+                            const int j = dirc > 0 ? w : J - 1 - w;
+                            rag_walk_lds(l, __builtin_amdgcn_readlane(nrag_v, j), nrmax, __double2loint(ragm.e), __double2hiint(ragm.e), ragm.ro,
+                                         lds_lane_addr, rag_R0, rag_R1, rag_R2, r1, r2, r3);
+                            const double f = F[j];
+                            farg[j] = fma(-f, fma(-f, fma(-f, r3, r2), r1), farg[j]);
                         }
-                        const double f = readlane_f64(fv_o, j);
-                        farg[j] = fma(-f, fma(-f, fma(-f, r3, r2), r1), farg[j]);
+                        rag_walk_settle(rag_R0, rag_R1, rag_R2);
+                    } else {
+#pragma nounroll
+                        for (int w = 0; w < J; ++w) {
+                            const int j = dirc > 0 ? w : J - 1 - w;
+                            const int nj = __builtin_amdgcn_readlane(nrag_v, j);
+                            for (; l < nj; ++l) {
+                                const double v = readlane_f64(ragm.e, l) * rag_R0, v2 = v * v;
+                                rag_R0 = rag_R1;
+                                rag_R1 = rag_R2;
+                                rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(l + 3, nrmax)));     // (the guard at the end)
+                                r1 += v;
+                                r2 = fma(v2, 0.5, r2);
+                                r3 = fma(v2 * v, 0.3333333333333333, r3);
+                            }
+                            const double f = readlane_f64(fv_o, j);
+                            farg[j] = fma(-f, fma(-f, fma(-f, r3, r2), r1), farg[j]);
+                        }
                     }
                     // (rare) sites of the ragged end with alpha max|R| between 3e-4 and 0.03, flagged by the producer: orders 4 to 8 of each, for
                     // the test sites whose windows hold it -- apart from the walk above
