@@ -76,6 +76,10 @@ PROTOTYPES = {
     'bmx_ctx_plan': (C.c_int, [_vp, _ip, _ip, _ip, _lp]),
     'bmx_ctx_launch_ranges': (C.c_int, [_vp, _lp, C.c_int32, _ip]),
     'bmx_ctx_surface': (C.c_int, [_vp, C.c_double, C.c_int64, C.c_int64, _dp, _ip]),
+    'bmx_comm_unique_id': (C.c_int, [C.c_char_p]),
+    'bmx_comm_create': (C.c_int, [C.POINTER(_vp), _vp, C.c_char_p, C.c_int32, C.c_int32]),
+    'bmx_comm_destroy': (None, [_vp]),
+    'bmx_comm_gather_records': (C.c_int, [_vp, _lp, C.c_int32, _vp, C.POINTER(_vp)]),
     'bmx_input_count': (C.c_int, [C.c_char_p, _lp]),
     'bmx_input_parse': (C.c_int, [C.c_char_p, C.c_int64, C.c_int, _lp, _dp, _lp, _lp]),
     'bmx_write_rows': (C.c_int, [C.c_char_p, C.c_int64, _lp, _dp, _dp, _ip, _ip, _ip, _ip, C.c_char_p, C.c_int,

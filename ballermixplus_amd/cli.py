@@ -159,7 +159,7 @@ def main(argv=None):
     say(("\n%s. Start computing likelihood ratios..." % (datetime.now())))
     # BMX_SHARD_BLOCK: test sites per shard block (default distributed.BLOCK = 4096; a multiple of 16 keeps every window's
     # arithmetic independent of the number of ranks) -- lets small inputs exercise real sharding in the tests
-    runner = world.sharded_runner(block=shard_block()) if world.distributed else None
+    runner = world.sharded_runner(block=shard_block(), balance=os.environ.get('BMX_SHARD_BALANCE') == '1') if world.distributed else None
     Scan(data, Neutral, Sel_Probs, grid, opt.outfile if world.rank == 0 else None, fixSize=opt.size, r=opt.w,
          s=opt.step, phys=opt.phys, noCenter=opt.noCenter, runner=runner, verbose=verbose, keep_results=False)
     stamp('table, scan, output')
@@ -237,7 +237,7 @@ def main_many(opt, files, stamp=lambda what: None):
     say('\nOptimizing over x= ' + ', '.join(['%g' % (x) for x in grid.x]))
     say('\n \t alpha= ' + ', '.join([str(a) for a in grid.abeta]))
     say('\n \t A= ' + ', '.join([str(A) for A in grid.A]))
-    runner = world.sharded_runner(block=shard_block()) if world.distributed else None
+    runner = world.sharded_runner(block=shard_block(), balance=os.environ.get('BMX_SHARD_BALANCE') == '1') if world.distributed else None
     nxt = {}
 
     def host_stage(i):

@@ -35,7 +35,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
 #include <errno.h>
+#include <rccl/rccl.h>     // types only: the library is opened with dlopen when a gather is first asked for
 
 #include <algorithm>
 #include <atomic>
@@ -4215,6 +4217,153 @@ int bmx_ctx_surface(bmx_ctx *c, double test_gen, int64_t win_lo, int64_t win_hi,
     HIP_TRY(hipMemcpyAsync(T_out, c->surf_T.p, (size_t)c->nA * c->npairs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (nsites_out) HIP_TRY(hipMemcpyAsync(nsites_out, c->surf_ns.p, (size_t)c->nA * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return BMX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------- RCCL gather
+// librccl.so through dlopen: only these entry points, resolved once
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+struct bmx_comm {
+    bmx_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    DevBuf<bmx_record> send, recv;
+};
+
+namespace {
+
+RcclApi *rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) { api.error = std::string("librccl.so cannot be opened: ") + dlerror(); return; }
+        auto sym = [&](const char *n) -> void * {
+            void *f = dlsym(api.handle, n);
+            if (!f && api.error.empty()) api.error = std::string("librccl.so lacks ") + n;
+            return f;
+        };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+        api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+        api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return &api;
+}
+
+#define RCCL_TRY(api, expr)                                                                                        \
+    do {                                                                                                           \
+        ncclResult_t r_ = (expr);                                                                                  \
+        if (r_ != ncclSuccess) return fail(BMX_E_HIP, std::string(#expr) + ": " + (api)->GetErrorString(r_));      \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int bmx_comm_unique_id(char *id) {
+    if (!id) return fail(BMX_E_INVALID, "id is NULL");
+    RcclApi *api = rccl_api();
+    if (!api->error.empty()) return fail(BMX_E_HIP, api->error);
+    static_assert(sizeof(ncclUniqueId) == BMX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    RCCL_TRY(api, api->GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return BMX_OK;
+}
+
+int bmx_comm_create(bmx_comm **out, bmx_ctx *c, const char *id, int32_t rank, int32_t world) {
+    if (!out || !c || !id) return fail(BMX_E_INVALID, "NULL argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(BMX_E_INVALID, "rank / world out of range");
+    RcclApi *api = rccl_api();
+    if (!api->error.empty()) return fail(BMX_E_HIP, api->error);
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(api, api->CommInitRank(&comm, world, u, rank));
+    bmx_comm *cm = new bmx_comm();
+    cm->ctx = c; cm->comm = comm; cm->rank = rank; cm->world = world;
+    *out = cm;
+    return BMX_OK;
+}
+
+void bmx_comm_destroy(bmx_comm *cm) {
+    if (!cm) return;
+    (void)hipSetDevice(cm->ctx->device);
+    RcclApi *api = rccl_api();
+    if (cm->comm && api->CommDestroy) (void)api->CommDestroy(cm->comm);
+    cm->send.release();
+    cm->recv.release();
+    delete cm;
+}
+
+int bmx_comm_gather_records(bmx_comm *cm, const int64_t *counts, int32_t root, bmx_record *dst_host, void **d_out) {
+    if (!cm || !counts) return fail(BMX_E_INVALID, "NULL argument");
+    if (root < 0 || root >= cm->world) return fail(BMX_E_INVALID, "root out of range");
+    RcclApi *api = rccl_api();
+    bmx_ctx *c = cm->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int64_t total = 0, my_off = 0;
+    for (int r = 0; r < cm->world; r++) {
+        if (counts[r] < 0) return fail(BMX_E_INVALID, "negative record count");
+        if (r < cm->rank) my_off += counts[r];
+        total += counts[r];
+    }
+    const int64_t mine = counts[cm->rank];
+    const bool is_root = cm->rank == root;
+    // this rank's records, packed: straight into the root's receive buffer at the rank's own offset, or into the send buffer
+    bmx_record *pack_to = nullptr;
+    if (is_root) {
+        HIP_TRY(cm->recv.ensure((size_t)total));
+        pack_to = cm->recv.p + my_off;
+    } else {
+        HIP_TRY(cm->send.ensure((size_t)mine));
+        pack_to = cm->send.p;
+    }
+    int64_t n = 0;
+    int rc = bmx_ctx_pack_records(c, pack_to, mine, 1, &n);
+    if (rc) return rc;
+    if (n != mine) return fail(BMX_E_INVALID, "gather_records: counts[rank] differs from the records this context holds");
+    // one group: the root posts a receive per peer (each at that rank's offset), every peer one send
+    RCCL_TRY(api, api->GroupStart());
+    if (is_root) {
+        int64_t off = 0;
+        for (int r = 0; r < cm->world; r++) {
+            if (r != root && counts[r] > 0)
+                RCCL_TRY(api, api->Recv(cm->recv.p + off, (size_t)counts[r] * sizeof(bmx_record), ncclChar, r, cm->comm, c->stream));
+            off += counts[r];
+        }
+    } else if (mine > 0) {
+        RCCL_TRY(api, api->Send(cm->send.p, (size_t)mine * sizeof(bmx_record), ncclChar, root, cm->comm, c->stream));
+    }
+    RCCL_TRY(api, api->GroupEnd());
+    if (is_root && dst_host && total > 0)
+        HIP_TRY(hipMemcpyAsync(dst_host, cm->recv.p, (size_t)total * sizeof(bmx_record), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (d_out) *d_out = is_root ? (void *)cm->recv.p : nullptr;
     return BMX_OK;
 }
 

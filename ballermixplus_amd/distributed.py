@@ -17,16 +17,48 @@ BLOCK = 4096   # test sites are dealt to ranks in blocks of this many (balances 
 RECORD = np.dtype([('clr', '<f8'), ('lin', '<i4'), ('nsites', '<i4')])     # bmx_record, include/bmxscan.h
 
 
-def assign(M, world, block=None):
-    """Index arrays, one per rank: blocks of `block` (default: BLOCK, read at call time) consecutive
-    test sites dealt round-robin."""
+def assign(M, world, block=None, weights=None):
+    """Index arrays, one per rank: blocks of `block` (default: BLOCK, read at call time) consecutive test sites, dealt
+    round-robin -- or, with `weights` (one estimate of the work per block: block_work), so that the ranks' total work is as
+    even as it gets: heaviest block first, each to the rank with the least work so far (ties: the lower rank), every
+    rank scanning its blocks in ascending order.  Blocks start on the same test sites either way, so no window's
+    arithmetic depends on the choice ("chunks balanced by estimated work")."""
     block = BLOCK if block is None else int(block)
     nblk = (M + block - 1) // block
+    owner = np.arange(nblk) % max(world, 1)
+    if weights is not None and world > 1:
+        w = np.asarray(weights, dtype=np.float64)
+        if len(w) != nblk:
+            raise ValueError('one weight per block is needed (%d blocks, %d weights)' % (nblk, len(w)))
+        load = np.zeros(world)
+        for b in np.argsort(-w, kind='stable'):
+            r = int(np.argmin(load))
+            owner[b] = r
+            load[r] += w[b]
     out = []
     for r in range(world):
-        parts = [np.arange(b * block, min((b + 1) * block, M), dtype=np.int64) for b in range(r, nblk, world)]
+        parts = [np.arange(b * block, min((b + 1) * block, M), dtype=np.int64) for b in np.flatnonzero(owner == r)]
         out.append(np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64))
     return out
+
+
+def block_work(genpos, As, zcut, test_gen, block=None):
+    """Estimated work of every block of `block` test sites: block length x sum over A of the window size W_A (sites with
+    A |g - t| <= zcut) at the block's middle test site -- what the scan's cost is proportional to, from two
+    binary searches per A.  The density of sites per genetic unit varies along a chromosome with the recombination map."""
+    block = BLOCK if block is None else int(block)
+    g = np.asarray(genpos, dtype=np.float64)
+    t = np.asarray(test_gen, dtype=np.float64)
+    M = len(t)
+    nblk = (M + block - 1) // block
+    starts = np.arange(nblk, dtype=np.int64) * block
+    lens = np.minimum(starts + block, M) - starts
+    mid = t[starts + lens // 2]
+    w = np.zeros(nblk)
+    for A in As:
+        r = float(zcut) / float(A)
+        w += np.searchsorted(g, mid + r, 'right') - np.searchsorted(g, mid - r, 'left')
+    return w * lens
 
 
 class _DevArray:
@@ -80,6 +112,18 @@ class World:
             if self._own_pg:
                 dist.destroy_process_group()
 
+    # ------------------------------------------------------------------ the library's own RCCL gather
+    def native_comm(self, ctx):
+        """engine.Comm over this world's ranks for `ctx`: rank 0 makes the RCCL id, the process group (any backend) carries its
+        128 bytes to the others, every rank joins.  After this the gather needs no torch: bmx_comm_gather_records moves the packed
+        records with ncclSend / ncclRecv on the context's own stream."""
+        from . import engine
+        box = [engine.Comm.make_id() if self.rank == 0 else None]
+        if self.distributed:
+            import torch.distributed as dist
+            dist.broadcast_object_list(box, src=0)
+        return engine.Comm(ctx, box[0], self.rank, self.size)
+
     # ------------------------------------------------------------------ gather
     def gather_records(self, rec, counts, dst=0):
         """ONE gather of 16-byte records to rank `dst`.  `rec`: this rank's records, either a numpy structured
@@ -110,12 +154,13 @@ class World:
         return [got[r, :counts[r]] for r in range(self.size)]
 
     # ------------------------------------------------------------------ runner
-    def sharded_runner(self, compute=None, block=None):
+    def sharded_runner(self, compute=None, block=None, balance=False):
         """A drop-in for engine.scan_batch that scans only this rank's test sites and gathers the records on
         rank 0 with ONE gather; the other ranks get None back (they write nothing).  Rank 0 gets a GatheredRecords: the
         per-rank record arrays as they arrived, which the native writer turns into rows directly (no reassembly in Python).
         `compute(sel, test_gen, lo, hi) -> (clr, lin, ns)` defaults to the GPU scan; tests inject a CPU function to
-        exercise the sharding on gloo."""
+        exercise the sharding on gloo.  balance=True (the CLI's BMX_SHARD_BALANCE=1): blocks go to the ranks by estimated work
+        (block_work on `sel.site_gen` / `sel.grid_A`) instead of round-robin -- same blocks, same rows, bitwise."""
         world = self
 
         def run(sel, test_gen, win_lo, win_hi):
@@ -124,7 +169,11 @@ class World:
             win_hi = np.asarray(win_hi, dtype=np.int64)
             M = len(test_gen)
             blk = BLOCK if block is None else int(block)
-            parts = assign(M, world.size, blk)
+            weights = None
+            if balance and world.size > 1:
+                from . import _lib
+                weights = block_work(sel.site_gen, sel.grid_A, _lib.lib().bmx_alpha_cut(), test_gen, blk)
+            parts = assign(M, world.size, blk, weights)
             mine = parts[world.rank]
             counts = [len(p) for p in parts]
             if compute is not None:
@@ -147,7 +196,7 @@ class World:
             got = world.gather_records(rec, counts)
             if got is None:
                 return None
-            return GatheredRecords(got, M, blk, world.size, len(sel.grid_x), len(sel.grid_abeta))
+            return GatheredRecords(got, M, blk, world.size, len(sel.grid_x), len(sel.grid_abeta), parts if weights is not None else None)
 
         return run
 
@@ -156,13 +205,14 @@ class GatheredRecords:
     """What rank 0 holds after the gather of a sharded scan: per_rank[r] = RECORD array of rank r's test sites in its own
     order (blocks of `block` test sites dealt round-robin)."""
 
-    def __init__(self, per_rank, M, block, world, nx, nab):
+    def __init__(self, per_rank, M, block, world, nx, nab, parts=None):
         self.per_rank, self.M, self.block, self.world, self.nx, self.nab = per_rank, M, block, world, nx, nab
+        self.parts = parts            # the ranks' test-site indices when they are not the round-robin deal (work-balanced runs)
 
     def in_order(self):
         """One RECORD array in test-site order."""
         out = np.empty(self.M, dtype=RECORD)
-        for r, p in enumerate(assign(self.M, self.world, self.block)):
+        for r, p in enumerate(self.parts if self.parts is not None else assign(self.M, self.world, self.block)):
             out[p] = self.per_rank[r]
         return out
 
@@ -174,7 +224,10 @@ class GatheredRecords:
     def write(self, path, phys, gen, xs, abs_, As):
         """Append the rows to `path` through the native writer, straight from the per-rank arrays."""
         from . import _lib
-        _lib.write_records(path, phys, gen, self.per_rank, self.block, xs, abs_, As)
+        if self.parts is not None:       # the native writer's rank order is the round-robin deal: reassemble first
+            _lib.write_records(path, phys, gen, [self.in_order()], self.block, xs, abs_, As)
+        else:
+            _lib.write_records(path, phys, gen, self.per_rank, self.block, xs, abs_, As)
 
 
 def unpack_lin(clr, lin, ns, nx, nab):

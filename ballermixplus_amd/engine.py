@@ -224,6 +224,47 @@ class Context:
         return psel, R
 
 
+class Comm:
+    """The library's own RCCL communicator (bmx_comm_*): one per (context, process group).  `make_id()` on rank 0, the 128 bytes
+    to the other ranks by any channel, then Comm(ctx, id, rank, world) on every rank (collective)."""
+
+    @staticmethod
+    def make_id():
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.lib().bmx_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx, comm_id, rank, world):
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        _lib.check(self._L.bmx_comm_create(C.byref(self._h), ctx._h, comm_id, self.rank, self.world))
+
+    def gather_records(self, counts, root=0, out=None):
+        """ONE gather of the context's packed records to `root` (ncclSend / ncclRecv inside the library, device to device).
+        Root: a RECORD array of sum(counts) records, rank after rank (`out` if given); other ranks: None."""
+        cnt = _lib.i64(counts)
+        if len(cnt) != self.world:
+            raise ValueError('one count per rank is needed')
+        rec = None
+        if self.rank == root:
+            rec = out if out is not None else np.empty(int(cnt.sum()), dtype=_lib.RECORD_DTYPE)
+        ptr = rec.ctypes.data_as(C.c_void_p) if rec is not None else None
+        _lib.check(self._L.bmx_comm_gather_records(self._h, _lib.as_lp(cnt), int(root), ptr, None))
+        return rec
+
+    def close(self):
+        if self._h:
+            self._L.bmx_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class NormalizedBetaBinom:
     """Drop-in for the reference class of the same name (v1:310-433): same constructor
     arguments; `get(x, a)` returns the per-site normalised selection probabilities.  The table
@@ -238,6 +279,7 @@ class NormalizedBetaBinom:
         self.stat = stat_name(nofreq, MAF, nosub)
         self.grid_x, self.grid_abeta, self.grid_A = Grids.scan_order()
         self._data = InputData
+        self.site_gen = InputData.genPos          # (work-balanced sharding estimates window sizes from the site positions)
         self._device = device
         self._bound_to = None
         self.ctx = None

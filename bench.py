@@ -489,8 +489,22 @@ def _run(args):
         host = torch.empty((max(mine_total, 1), 2), dtype=torch.int64).pin_memory()
         host_np = host.numpy().view(rec_dt).reshape(-1)
 
+    # BMX_NATIVE_GATHER=1: the gather inside libbmxscan (bmx_comm_gather_records: ncclSend / ncclRecv on the context's stream, no
+    # torch in the data path; torch.distributed only carries the 128-byte RCCL id once).  Not the default: with one GPU per box
+    # it could only be run with a single rank (tests/test_gpu_round4.py), N > 1 is unmeasured.
+    native = {'comm': None}
+    if os.environ.get('BMX_NATIVE_GATHER') == '1' and world.distributed and on_gpu:
+        native['comm'] = world.native_comm(ctx)
+        native['host'] = np.empty(int(counts_by_rank.sum()), dtype=rec_dt) if rank == 0 else None
+        native['offs'] = np.concatenate(([0], np.cumsum(counts_by_rank)))
+
     def collect():
         """All records of this rank's slots -> the host (one process) or rank 0 (ONE gather)."""
+        if native['comm'] is not None:
+            got = native['comm'].gather_records(counts_by_rank, root=0, out=native['host'])
+            if rank != 0:
+                return None
+            return [got[int(native['offs'][r]):int(native['offs'][r + 1])] for r in range(world.size)]
         if world.distributed:
             if on_gpu:       # device -> device pack, then RCCL
                 ctx.pack_records(device_ptr=send.data_ptr(), cap=pad)
@@ -545,10 +559,15 @@ def _run(args):
     # location, the planning / counting pass, the scans, the result transfer (what a caller of the C ABI pays once per genome)
     t_cold, cold = None, None
     if not args.no_cold_pass:
+        if native['comm'] is not None:
+            native['comm'].close()
         ctx.close()
         barrier()
         t0 = time.perf_counter()
         ctx = engine.Context(dev)
+        if native['comm'] is not None:
+            native['comm'].close()
+            native['comm'] = world.native_comm(ctx)
         ctx.set_variant(args.variant)
         ctx.set_model(model, As)
         for ci, (gen, k, nn) in enumerate(chroms):
@@ -682,6 +701,8 @@ def _run(args):
         line = json.dumps(res)
     else:
         line = None
+    if native['comm'] is not None:
+        native['comm'].close()
     ctx.close()
     world.finish()
     return line

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define BMX_ABI_VERSION_MAJOR 1
-#define BMX_ABI_VERSION_MINOR 3
+#define BMX_ABI_VERSION_MINOR 4
 
 enum {
     BMX_OK = 0,
@@ -204,6 +204,24 @@ int bmx_ctx_plan(bmx_ctx *c, int32_t *J, int32_t *use_lds, int32_t *mode, int64_
  * A window's result must not depend on the cut -- the parity tests recompute the windows on either side of every cut
  * independently.  Valid once the test sites are set. */
 int bmx_ctx_launch_ranges(bmx_ctx *c, int64_t *offs, int32_t cap, int32_t *n_out);
+
+/* ---- the final gather over RCCL, inside the library (north_star: "only a final RCCL gather over xGMI") --
+ * One process per GPU, each with its own context.  Rank 0 makes an id (bmx_comm_unique_id: 128 bytes) and hands it to the other
+ * ranks by whatever channel the caller has (MPI, a file, a socket, torch's store); every rank then calls bmx_comm_create with
+ * its context -- collectively, like ncclCommInitRank.  librccl.so is opened when the first of these functions is called
+ * (dlopen): a program that never gathers never loads it.  No torch, no Python. */
+typedef struct bmx_comm bmx_comm;
+#define BMX_COMM_ID_BYTES 128
+int bmx_comm_unique_id(char *id /* BMX_COMM_ID_BYTES */);
+int bmx_comm_create(bmx_comm **out, bmx_ctx *c, const char *id, int32_t rank, int32_t world);
+void bmx_comm_destroy(bmx_comm *cm);
+/* ONE gather of the records of every slot of the communicator's context that holds results (slot order, as
+ * bmx_ctx_pack_records) to rank `root`: the packed bmx_record buffers move device to device in one group of ncclSend /
+ * ncclRecv on the context's stream -- every peer has its own xGMI link to the root, nothing goes to the other ranks.
+ * counts[world]: the number of records of every rank (each rank knows them all: test sites are dealt deterministically).
+ * On the root, dst_host (may be NULL) receives all records, rank after rank, and *d_out (may be NULL) the device address of
+ * the same array (valid until the next gather or bmx_comm_destroy); other ranks ignore both.  Collective; blocks until done. */
+int bmx_comm_gather_records(bmx_comm *cm, const int64_t *counts, int32_t root, bmx_record *dst_host, void **d_out);
 
 /* ---- input ingest (host only) ------------------------------ */
 /* Native reader of the 4-column input that InputData.readCounts / readPolyCalls parse line by

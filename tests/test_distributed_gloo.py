@@ -135,3 +135,100 @@ def test_unpack_lin_roundtrip():
     lin = np.array([-1, 0, 509, 510, 15809], dtype=np.int32)
     clr, ix, ia, iA, ns = distributed.unpack_lin(np.zeros(5), lin, np.zeros(5, np.int32), 10, 51)
     assert iA.tolist() == [-1, 0, 0, 1, 30] and ix.tolist() == [-1, 0, 9, 0, 9] and ia.tolist() == [-1, 0, 50, 0, 50]
+
+
+# ------------------------------------------------------------------------------------------------ work-balanced blocks
+def _warped_case():
+    """Example 1 with the second half of the chromosome five times denser per genetic unit (a cold region of the recombination
+    map): windows there hold five times the sites, so equal-count blocks are unequal work."""
+    sys.path.insert(0, HERE)
+    import cases
+    argv, gold = cases.ALL_CASES['ex1_B2']
+    opt, case, ts = cases.host_side(argv)
+    g = np.asarray(case.data.genPos, dtype=np.float64)
+    h = len(g) // 2
+    gen = np.where(np.arange(len(g)) < h, g, g[h] + (g - g[h]) * 0.2)
+    assert np.all(np.diff(gen) >= 0)
+    return case, gen
+
+
+def _balanced_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from util import c_oracle, c_scan
+    from ballermixplus_amd import distributed
+    w = distributed.World.from_env(backend='gloo')
+    case, gen = _warped_case()
+    m = case.oracle_model()
+    L = c_oracle()
+    nx, nab = len(case.xs), len(case.abetas)
+    N = len(gen)
+
+    def compute(sel, tg, lo, hi):
+        clr, ix, ia, iA, ns = c_scan(L, m.R, case.As, gen, m.row, tg, lo, hi)
+        return clr, np.where(iA < 0, -1, (iA * nx + ix) * nab + ia).astype(np.int32), ns
+
+    class Sel:
+        grid_x, grid_abeta, grid_A, site_gen = case.xs, case.abetas, case.As, gen
+
+    tg = gen[::3]                              # every third site a test site: 253 windows in blocks of 16
+    M = len(tg)
+    lo, hi = np.zeros(M, np.int64), np.full(M, N - 1, np.int64)
+    out = {}
+    for balance in (False, True):
+        res = w.sharded_runner(compute=compute, block=16, balance=balance)(Sel, tg, lo, hi)
+        if rank == 0:
+            assert (res.parts is not None) == balance
+            out[balance] = [np.asarray(a) for a in res.unpack()]
+            import tempfile
+            with tempfile.TemporaryDirectory() as d:      # the writer takes either layout
+                f = os.path.join(d, 'rows.txt')
+                res.write(f, np.arange(M, dtype=np.int64), tg, [repr(v) for v in case.xs], [repr(v) for v in case.abetas], [repr(v) for v in case.As])
+                out[('rows', balance)] = open(f, 'rb').read()
+    if rank == 0:
+        q.put(out)
+    w.finish()
+
+
+def test_work_balanced_blocks_change_no_row():
+    """blocks dealt by estimated work (sum_A W_A) instead of round-robin.  Two ranks over gloo on a chromosome whose
+    second half is five times denser: the same rows bitwise, from either assignment, as one process; and the heavier rank's
+    share of the work drops."""
+    import torch.multiprocessing as mp
+    from ballermixplus_amd import _lib, distributed
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_balanced_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sys.path.insert(0, HERE)
+    from util import c_oracle, c_scan
+    case, gen = _warped_case()
+    m = case.oracle_model()
+    N = len(gen)
+    tg = gen[::3]
+    M = len(tg)
+    ref = c_scan(c_oracle(), m.R, case.As, gen, m.row, tg, np.zeros(M, np.int64), np.full(M, N - 1, np.int64))
+    for balance in (False, True):
+        for a, b in zip(got[balance], ref):
+            assert np.array_equal(a, b)
+    assert got[('rows', False)] == got[('rows', True)] and len(got[('rows', True)]) > 10000
+    # what the estimate buys on this chromosome: the heavier rank's share of the (exactly counted) window work
+    zcut = _lib.lib().bmx_alpha_cut()
+    w = distributed.block_work(gen, case.As, zcut, tg, 16)
+    exact = np.zeros(M)
+    for A in case.As:
+        r = zcut / float(A)
+        exact += np.searchsorted(gen, tg + r, 'right') - np.searchsorted(gen, tg - r, 'left')
+    share = lambda parts: max(exact[p].sum() for p in parts) / exact.sum()
+    rr, bal = share(distributed.assign(M, 2, 16)), share(distributed.assign(M, 2, 16, w))
+    print('heavier rank holds %.1f %% of the work round-robin, %.1f %% balanced' % (100 * rr, 100 * bal))
+    assert bal <= rr + 1e-12 and bal < 0.52
+    with pytest.raises(ValueError):
+        distributed.assign(M, 2, 16, w[:-1])

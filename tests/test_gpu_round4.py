@@ -155,3 +155,61 @@ def test_config5_every_contig_against_the_oracle():
     print('config 5 vs C oracle (own table): %d windows on 8 contigs, worst rel dCLR %.3e, worst abs %.3e, %d rounding-noise ties'
           % (total, worst, worst_abs, ties))
     assert worst < 1e-6
+
+
+def test_native_rccl_gather_with_one_rank():
+    """bmx_comm_*: the library's own RCCL communicator (librccl.so through dlopen, ncclCommInitRank on the context's device) and
+    ONE gather of the packed records of two chromosome slots -- with a single rank the group holds no send / receive, the path
+    through ncclGroupStart / ncclGroupEnd, the packing into the receive buffer and the copy to the host is the same one N ranks
+    take.  (N > 1 needs N GPUs: RCCL refuses two ranks on one device.  Not run on this 1-GPU box.)"""
+    from ballermixplus_amd import _lib, engine as eng, synth
+    from ballermixplus_amd.hostmodel import Grids
+    xs, ab, As = Grids(None, None, False, False, None, None).scan_order()
+    data = [synth.synth_chromosome(60000, 100, c + 1) for c in range(2)]
+    spect = {(a, b): f for a, b, f in synth.spect_from_counts(np.concatenate([d[2] for d in data]), np.concatenate([d[3] for d in data]))}
+    model = eng.ModelArrays('B2', 1, [100], spect, {100: 1.0}, xs, ab)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    for c, (phys, gen, k, nn) in enumerate(data):
+        idx = np.arange(20000, 20000 + 4096 * (c + 1))
+        ctx.select_slot(c)
+        ctx.set_sites(gen, model.rows_of(k, nn))
+        ctx.set_tests(gen[idx], np.zeros(len(idx), np.int64), np.full(len(idx), len(gen) - 1, np.int64))
+        ctx.scan()
+    want = ctx.pack_records()
+    assert len(want) == 4096 * 3
+    comm = eng.Comm(ctx, eng.Comm.make_id(), 0, 1)
+    got = comm.gather_records([len(want)], root=0)
+    assert np.array_equal(got, want)
+    again = comm.gather_records([len(want)], root=0, out=np.empty(len(want), dtype=_lib.RECORD_DTYPE))      # buffers are reused
+    assert np.array_equal(again, want)
+    with pytest.raises(_lib.BmxError):           # counts must say what the context holds
+        comm.gather_records([len(want) - 1], root=0)
+    with pytest.raises(ValueError):
+        comm.gather_records([1, 2], root=0)
+    comm.close()
+    ctx.close()
+
+
+def test_bench_step_through_the_native_gather():
+    """bench.py with BMX_NATIVE_GATHER=1 and the process group forced on for a single rank: every step's records go through
+    bmx_comm_gather_records (the library's own ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd path) instead of
+    torch.distributed.gather; same checksum and parity sample as the plain run."""
+    import json
+    import subprocess
+    from util import REPO
+    env = dict(os.environ, BMX_FORCE_DIST='1', BMX_NATIVE_GATHER='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29673')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'BMX_DIST_BACKEND', 'BMX_SINGLE_DEVICE'):
+        env.pop(k, None)
+    common = [sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '2', '--warmup', '1', '--total-snps', '400000', '--no-cpu-baseline']
+    r = subprocess.run(common, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['config']['records_per_step'] == d['config']['windows_per_step'] and d['parity_sample']['mismatches'] == 0
+    assert 'bitwise equal to the timed steps\': True' in d['config']['end_to_end_note']
+    for k in ('BMX_FORCE_DIST', 'BMX_NATIVE_GATHER'):
+        env.pop(k)
+    r1 = subprocess.run(common, capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith('{')][-1])
+    assert d1['config']['checksum_clr'] == pytest.approx(d['config']['checksum_clr'], rel=1e-12)
