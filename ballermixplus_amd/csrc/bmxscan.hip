@@ -2546,12 +2546,23 @@ constexpr int SOLO_MAGIC = 0x50100000;
 constexpr int SOLO_S0 = 256, SOLO_S1 = 192;        // staging lists per wave: E of the most frequent row / (E, row offset) of the others
 // Far field of the solo kernels: order 8 on |x| <= 0.05 (the round-2 series).  The per-row thresholds on the device are
 // those of the grouped kernels (P_EPS): a site is far here S_SHIFT = log(P_EPS / S_EPS) later.
+#ifndef BMX_S_ORDER
+#define BMX_S_ORDER 8
+#endif
+#if BMX_S_ORDER == 8
 constexpr int S_ORDER = 8, S_COPIES = 8, S_MOM = 1 + S_ORDER / 2, S_FAR_CAP = 8192;
 // (S_EPS = 0.05)
 constexpr double S_SHIFT = P_ORDER == 16 ? 1.6095 : P_ORDER == 12 ? 1.0987 : 0.0;
 __device__ constexpr double S_W[8] = {0.9999999999998467, 0.4999999999996164, 0.3333333341509627, 0.25000000122701976,
                                       0.19999882322703955, 0.16666529319200146, 0.1434841013671569, 0.12562715480255862};
 __device__ constexpr double S_D[6] = {7.94, 5.13, 3.462, 2.357, 1.571, 0.985};
+#else
+// the prepared group kernels' series (order P_ORDER on |x| <= P_EPS): fewer near entries, longer Horner chains per occupied row
+constexpr int S_ORDER = P_ORDER, S_COPIES = P_COPIES, S_MOM = 1 + S_ORDER / 2, S_FAR_CAP = P_FAR_CAP;
+constexpr double S_SHIFT = 0.0;
+#define S_W P_W
+#define S_D P_D
+#endif
 
 template <bool FILL>
 __global__ __launch_bounds__(PREP_THREADS) void prep_solo_kernel(PrepParams P) {
