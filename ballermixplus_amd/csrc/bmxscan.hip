@@ -103,8 +103,14 @@ constexpr int MOM_SLOTS_LDS = 64;             // ... of which this many are used
 #ifndef BMX_PAIR_PREFETCH
 #define BMX_PAIR_PREFETCH (!USE_LDS)      // pair blocks one block ahead: pays for R from global memory only (LDS: 64.22 vs 64.03 ms)
 #endif
+#ifndef BMX_PPAIR_PREFETCH
+#define BMX_PPAIR_PREFETCH 1              // prepared kernel, pair blocks one block ahead: round 4 (no spills, 13 spare VGPRs): +0.4 % with the table in LDS too
+#endif
 #ifndef BMX_FOLD_RPRE
 #define BMX_FOLD_RPRE (!USE_LDS)          // rows of a fold batch requested with its moments: global memory only (LDS: 64.51 vs 64.03 ms)
+#endif
+#ifndef BMX_FOLD_EARLY
+#define BMX_FOLD_EARLY (!USE_LDS)         // prepared kernel's fold: heads and R of the next two slots requested before this step's powers
 #endif
 #ifndef BMX_MIDTRI
 #define BMX_MIDTRI 1
@@ -2102,7 +2108,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     const int pend_hi = ((__builtin_amdgcn_readfirstlane(__double2hiint(op)) >> 20) & 0x7ff) - 1022;
                     const int span8 = 8 * min(max(pend_hi, pend_lo), 125);
                     double Rp[BS], ep[BS];
-                    if (BMX_PAIR_PREFETCH) {
+                    if (BMX_PPAIR_PREFETCH) {
                         const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
 #pragma unroll
                         for (int u = 0; u < BS; ++u) {
@@ -2116,7 +2122,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
                         spend(span8 * BS / 8);
                         double v[BS];
-                        if (BMX_PAIR_PREFETCH) {
+                        if (BMX_PPAIR_PREFETCH) {
 #pragma unroll
                             for (int u = 0; u < BS; ++u) v[u] = ep[u] * Rp[u];
 #pragma unroll
@@ -2288,7 +2294,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                 // two slots per step.  With the table in L2 / HBM the heads (M_1, row) and the R of the NEXT two are requested before this
                 // step's powers (+3.4 / +4.2 % at 11 / 41 sample sizes); with the table in LDS the extra live values cost more than the
                 // short latency (-0.7 %), so that form asks for its R where it needs it
-                if (!USE_LDS && n_occ > 0) {
+                if (BMX_FOLD_EARLY && n_occ > 0) {
                     need();
                     const ScratchEnt *rp0 = ring + (pos & (RING_UNITS - 1));
                     ScratchEnt ua = rp0[0], ub = rp0[n_occ > 1 ? PREP_MOM : 0];
@@ -2308,7 +2314,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         pos += two ? 2 * PREP_MOM : PREP_MOM;
                     }
                 }
-                if (USE_LDS) {
+                if (!BMX_FOLD_EARLY) {
                     for (int s = 0; s < n_occ; s += 2) {
                         need();
                         const ScratchEnt *rp = ring + (pos & (RING_UNITS - 1));
