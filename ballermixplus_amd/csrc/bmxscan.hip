@@ -1851,6 +1851,46 @@ __device__ __forceinline__ void rag_walk_lds(int &l, int nj, int nrmax, int e_lo
 __device__ __forceinline__ void rag_walk_settle(double &R0, double &R1, double &R2) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2) : : "memory");
 }
+// ... the same walk with the R table in global memory / L2 (tables too large for LDS): row offsets are indices into the table
+// (row * NP), the load is global_load_dwordx2 with the slice's base in a scalar pair, and the wait is on vmcnt
+__device__ __forceinline__ void rag_walk_global(int &l, int nj, int nrmax, int e_lo, int e_hi, int ro, unsigned lane8, const char *Rb,
+                                                double &R0, double &R1, double &R2, double &p0, double &p1, double &p2) {
+    int tmp;
+    unsigned addr;
+    double v, v2;
+    const double third = 0.3333333333333333;
+    asm volatile(
+        "s_cmp_ge_i32 %[l], %[nj]\n\t"
+        "s_cbranch_scc1 2f\n"
+        "1:\n\t"
+        "v_readlane_b32 vcc_lo, %[elo], %[l]\n\t"
+        "v_readlane_b32 vcc_hi, %[ehi], %[l]\n\t"
+        "s_add_i32 %[tmp], %[l], 3\n\t"
+        "s_min_i32 %[tmp], %[tmp], %[nrmax]\n\t"
+        "v_readlane_b32 %[tmp], %[ro], %[tmp]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_mul_f64 %[v], %[R0], vcc\n\t"
+        "v_mov_b64 %[R0], %[R1]\n\t"
+        "v_mov_b64 %[R1], %[R2]\n\t"
+        "v_lshl_add_u32 %[addr], %[tmp], 3, %[lane]\n\t"
+        "global_load_dwordx2 %[R2], %[addr], %[base]\n\t"
+        "v_mul_f64 %[v2], %[v], %[v]\n\t"
+        "v_add_f64 %[p0], %[p0], %[v]\n\t"
+        "v_fma_f64 %[p1], %[v2], 0.5, %[p1]\n\t"
+        "v_mul_f64 %[v2], %[v2], %[v]\n\t"
+        "v_fma_f64 %[p2], %[v2], %[third], %[p2]\n\t"
+        "s_add_i32 %[l], %[l], 1\n\t"
+        "s_cmp_lt_i32 %[l], %[nj]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:\n\t"
+        : [l] "+s"(l), [R0] "+v"(R0), [R1] "+v"(R1), [R2] "+v"(R2), [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2),
+          [tmp] "=&s"(tmp), [v] "=&v"(v), [v2] "=&v"(v2), [addr] "=&v"(addr)
+        : [nj] "s"(nj), [nrmax] "s"(nrmax), [elo] "v"(e_lo), [ehi] "v"(e_hi), [ro] "v"(ro), [lane] "v"(lane8), [base] "s"(Rb), [third] "s"(third)
+        : "vcc", "scc", "memory");
+}
+__device__ __forceinline__ void rag_walk_settle_global(double &R0, double &R1, double &R2) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2) : : "memory");
+}
 
 struct PrepView {
     const ScratchEnt *arena;
@@ -2226,22 +2266,15 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                         }
                         rag_walk_settle(rag_R0, rag_R1, rag_R2);
                     } else {
-#pragma nounroll
+#pragma unroll
                         for (int w = 0; w < J; ++w) {
                             const int j = dirc > 0 ? w : J - 1 - w;
-                            const int nj = __builtin_amdgcn_readlane(nrag_v, j);
-                            for (; l < nj; ++l) {
-                                const double v = readlane_f64(ragm.e, l) * rag_R0, v2 = v * v;
-                                rag_R0 = rag_R1;
-                                rag_R1 = rag_R2;
-                                rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(l + 3, nrmax)));     // (the guard at the end)
-                                r1 += v;
-                                r2 = fma(v2, 0.5, r2);
-                                r3 = fma(v2 * v, 0.3333333333333333, r3);
-                            }
-                            const double f = readlane_f64(fv_o, j);
+                            rag_walk_global(l, __builtin_amdgcn_readlane(nrag_v, j), nrmax, __double2loint(ragm.e), __double2hiint(ragm.e), ragm.ro,
+                                            lane8, Rb, rag_R0, rag_R1, rag_R2, r1, r2, r3);
+                            const double f = F[j];
                             farg[j] = fma(-f, fma(-f, fma(-f, r3, r2), r1), farg[j]);
                         }
+                        rag_walk_settle_global(rag_R0, rag_R1, rag_R2);
                     }
                     // (rare) sites of the ragged end with alpha max|R| between 3e-4 and 0.03, flagged by the producer: orders 4 to 8 of each, for
                     // the test sites whose windows hold it -- apart from the walk above
