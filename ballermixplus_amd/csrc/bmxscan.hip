@@ -1428,7 +1428,7 @@ constexpr int RING_UNITS = 256, RING_MIRROR = 32, AUX_UNITS = 32;     // per wav
 constexpr int PREP_ZONE_DONE = -0x7fffffff;
 constexpr int PREP_THREADS = 256;
 constexpr int PREP_THR_LDS_MAX = 4096;                                // rows whose far thresholds are staged in LDS
-constexpr int64_t SOLO_GAP = 12;                                      // median gap between test sites beyond which groups stop paying
+constexpr int64_t SOLO_GAP = 9;                                       // median gap between test sites beyond which groups stop paying (round 4: J = 8 1.66 / 1.54 M, solo 1.57 / 1.58 M windows/s at stride 9 / 10)
 
 struct PrepParams {
     const double *genpos;
@@ -3779,7 +3779,8 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
     // prepared kernels (windows/s x1000 for J = 16 / 8 / 4 / one test site per wave; profiles/r03_stride_table.txt): stride 1:
     // 4175/-/-/-, 2: 3133/2860/1774/1339, 4: -/2433/1677/1343, 6: -/2058/1543/1342, 8: -/1741/1474/1337, 12: -/1354/1298/1333,
     // 16: -/1157/1158/1322, 24: -/916/957/1314, 32: -/772/836/1301, 48: -/585/687/1282, 64+: 1268 ... 1174 at 200
-    // -> J = 16 up to a median gap of 3 sites between test sites, 8 up to 12, beyond that one test site per wave.
+    // -> J = 16 up to a median gap of 3 sites between test sites, 8 up to 12 (round 4: up to 9, the solo pipeline having gained 15 %),
+    //    beyond that one test site per wave.
     // (The round-2 kernels, variant 12, keep their own thresholds: 16 / 8 / 4 up to 3 / 28 / 56, then the per-site kernel.)
     const int64_t gap_max = diag_env("BMX_DENSE_GAP") ? atoll(diag_env("BMX_DENSE_GAP")) : 56;
     const bool can_group = s->tests_sorted && s->test_gap <= gap_max && c->span_hi <= 62 && s->N < 0x7fffffffLL && c->nA < 8191 && !P.wide_tab;
