@@ -52,3 +52,28 @@ def test_cli_scan_without_a_gpu_fails_loudly(tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and 'no CPU fallback' in (r.stderr + r.stdout)
     assert not (tmp_path / 'o.txt').exists()
+
+
+def test_input_list_and_shard_block_helpers(tmp_path, monkeypatch, capsys):
+    """--inputs list files (comments and blank lines wherever they are indented, relative names against the list's own directory)
+    and BMX_SHARD_BLOCK (a positive multiple of 16, checked for the one-file and the many-file form alike)."""
+    from ballermixplus_amd import cli
+    sub = tmp_path / 'lists'
+    sub.mkdir()
+    lst = sub / 'genome.txt'
+    lst.write_text('# whole genome\nchr1.txt\n   # an indented comment\n\n  sub/chr2.txt  \n/abs/chr3.txt\n')
+    assert cli.input_list(str(lst)) == [str(sub / 'chr1.txt'), str(sub / 'sub/chr2.txt'), '/abs/chr3.txt']
+    monkeypatch.delenv('BMX_SHARD_BLOCK', raising=False)
+    assert cli.shard_block() is None
+    monkeypatch.setenv('BMX_SHARD_BLOCK', '64')
+    assert cli.shard_block() == 64
+    for bad in ('0', '-16', '24', 'many'):
+        monkeypatch.setenv('BMX_SHARD_BLOCK', bad)
+        with pytest.raises(SystemExit):
+            cli.shard_block()
+    assert 'multiple of 16' in capsys.readouterr().out
+    # --inputs together with a helper-file step is refused with a message (it used to fall through with infile = None)
+    with pytest.raises(SystemExit):
+        cli.main(['--inputs', str(lst), '--spect', str(tmp_path / 's.txt'), '--getSpect'])
+    assert '--inputs lists files to scan' in capsys.readouterr().out
+    assert cli.output_name(str(tmp_path / 'out_{}.tsv'), '/x/chr7.txt') == str(tmp_path / 'out_chr7.tsv')
