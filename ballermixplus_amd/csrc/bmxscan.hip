@@ -1852,44 +1852,90 @@ __device__ __forceinline__ void rag_walk_settle(double &R0, double &R1, double &
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2) : : "memory");
 }
 // ... the same walk with the R table in global memory / L2 (tables too large for LDS): row offsets are indices into the table
-// (row * NP), the load is global_load_dwordx2 with the slice's base in a scalar pair, and the wait is on vmcnt
-__device__ __forceinline__ void rag_walk_global(int &l, int nj, int nrmax, int e_lo, int e_hi, int ro, unsigned lane8, const char *Rb,
-                                                double &R0, double &R1, double &R2, double &p0, double &p1, double &p2) {
+// (row * NP), the load is global_load_dwordx2 with the slice's base in a scalar pair, and the wait is on vmcnt.  Here the three R
+// registers are taken in turn, RA -> RB -> RC -> RA, with the turn `ph` carried from statement to statement: the R of entry l was
+// requested three entries ago and the walk waits for exactly that one (vmcnt(2): loads return in order), no register is moved.
+// Same box, 262k-window blocks: 11 / 41 sample sizes per file 3.459 -> 3.504 / 2.638 -> 2.710 M windows/s.  With the table in LDS
+// the same form measured 0.4-0.8 % SLOWER than the rotation (three more scalar compares and branches per statement, for a latency
+// that is short there), so rag_walk_lds keeps it.
+__device__ __forceinline__ void rag_walk_global(int &l, int &ph, int nj, int nrmax, int e_lo, int e_hi, int ro, unsigned lane8, const char *Rb,
+                                             double &RA, double &RB, double &RC, double &p0, double &p1, double &p2) {
     int tmp;
     unsigned addr;
     double v, v2;
     const double third = 0.3333333333333333;
     asm volatile(
         "s_cmp_ge_i32 %[l], %[nj]\n\t"
-        "s_cbranch_scc1 2f\n"
+        "s_cbranch_scc1 9f\n\t"
+        "s_cmp_eq_u32 %[ph], 1\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_cmp_eq_u32 %[ph], 2\n\t"
+        "s_cbranch_scc1 3f\n"
         "1:\n\t"
         "v_readlane_b32 vcc_lo, %[elo], %[l]\n\t"
         "v_readlane_b32 vcc_hi, %[ehi], %[l]\n\t"
         "s_add_i32 %[tmp], %[l], 3\n\t"
         "s_min_i32 %[tmp], %[tmp], %[nrmax]\n\t"
         "v_readlane_b32 %[tmp], %[ro], %[tmp]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_mul_f64 %[v], %[R0], vcc\n\t"
-        "v_mov_b64 %[R0], %[R1]\n\t"
-        "v_mov_b64 %[R1], %[R2]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_mul_f64 %[v], %[RA], vcc\n\t"
         "v_lshl_add_u32 %[addr], %[tmp], 3, %[lane]\n\t"
-        "global_load_dwordx2 %[R2], %[addr], %[base]\n\t"
+        "global_load_dwordx2 %[RA], %[addr], %[base]\n\t"
         "v_mul_f64 %[v2], %[v], %[v]\n\t"
         "v_add_f64 %[p0], %[p0], %[v]\n\t"
         "v_fma_f64 %[p1], %[v2], 0.5, %[p1]\n\t"
         "v_mul_f64 %[v2], %[v2], %[v]\n\t"
         "v_fma_f64 %[p2], %[v2], %[third], %[p2]\n\t"
         "s_add_i32 %[l], %[l], 1\n\t"
+        "s_mov_b32 %[ph], 1\n\t"
+        "s_cmp_ge_i32 %[l], %[nj]\n\t"
+        "s_cbranch_scc1 9f\n"
+        "2:\n\t"
+        "v_readlane_b32 vcc_lo, %[elo], %[l]\n\t"
+        "v_readlane_b32 vcc_hi, %[ehi], %[l]\n\t"
+        "s_add_i32 %[tmp], %[l], 3\n\t"
+        "s_min_i32 %[tmp], %[tmp], %[nrmax]\n\t"
+        "v_readlane_b32 %[tmp], %[ro], %[tmp]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_mul_f64 %[v], %[RB], vcc\n\t"
+        "v_lshl_add_u32 %[addr], %[tmp], 3, %[lane]\n\t"
+        "global_load_dwordx2 %[RB], %[addr], %[base]\n\t"
+        "v_mul_f64 %[v2], %[v], %[v]\n\t"
+        "v_add_f64 %[p0], %[p0], %[v]\n\t"
+        "v_fma_f64 %[p1], %[v2], 0.5, %[p1]\n\t"
+        "v_mul_f64 %[v2], %[v2], %[v]\n\t"
+        "v_fma_f64 %[p2], %[v2], %[third], %[p2]\n\t"
+        "s_add_i32 %[l], %[l], 1\n\t"
+        "s_mov_b32 %[ph], 2\n\t"
+        "s_cmp_ge_i32 %[l], %[nj]\n\t"
+        "s_cbranch_scc1 9f\n"
+        "3:\n\t"
+        "v_readlane_b32 vcc_lo, %[elo], %[l]\n\t"
+        "v_readlane_b32 vcc_hi, %[ehi], %[l]\n\t"
+        "s_add_i32 %[tmp], %[l], 3\n\t"
+        "s_min_i32 %[tmp], %[tmp], %[nrmax]\n\t"
+        "v_readlane_b32 %[tmp], %[ro], %[tmp]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_mul_f64 %[v], %[RC], vcc\n\t"
+        "v_lshl_add_u32 %[addr], %[tmp], 3, %[lane]\n\t"
+        "global_load_dwordx2 %[RC], %[addr], %[base]\n\t"
+        "v_mul_f64 %[v2], %[v], %[v]\n\t"
+        "v_add_f64 %[p0], %[p0], %[v]\n\t"
+        "v_fma_f64 %[p1], %[v2], 0.5, %[p1]\n\t"
+        "v_mul_f64 %[v2], %[v2], %[v]\n\t"
+        "v_fma_f64 %[p2], %[v2], %[third], %[p2]\n\t"
+        "s_add_i32 %[l], %[l], 1\n\t"
+        "s_mov_b32 %[ph], 0\n\t"
         "s_cmp_lt_i32 %[l], %[nj]\n\t"
         "s_cbranch_scc1 1b\n"
-        "2:\n\t"
-        : [l] "+s"(l), [R0] "+v"(R0), [R1] "+v"(R1), [R2] "+v"(R2), [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2),
+        "9:\n\t"
+        : [l] "+s"(l), [ph] "+s"(ph), [RA] "+v"(RA), [RB] "+v"(RB), [RC] "+v"(RC), [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2),
           [tmp] "=&s"(tmp), [v] "=&v"(v), [v2] "=&v"(v2), [addr] "=&v"(addr)
         : [nj] "s"(nj), [nrmax] "s"(nrmax), [elo] "v"(e_lo), [ehi] "v"(e_hi), [ro] "v"(ro), [lane] "v"(lane8), [base] "s"(Rb), [third] "s"(third)
         : "vcc", "scc", "memory");
 }
-__device__ __forceinline__ void rag_walk_settle_global(double &R0, double &R1, double &R2) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2) : : "memory");
+__device__ __forceinline__ void rag_walk_settle_global(double &RA, double &RB, double &RC) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(RA), "+v"(RB), "+v"(RC) : : "memory");
 }
 
 struct PrepView {
@@ -2253,7 +2299,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     double rag_R2 = loadR(__builtin_amdgcn_readlane(ragm.ro, min(2, nrmax)));
                     const int nrag_v = nragv_o;
                     double r1 = 0.0, r2 = 0.0, r3 = 0.0;
-                    int l = 0;
+                    int l = 0, ph = 0;            // the walk's position and whose turn it is among rag_R0 / rag_R1 / rag_R2
                     if (USE_LDS) {
                         // the walk itself is one asm statement per test site (rag_walk_lds): no control flow inside the unrolled loop
 #pragma unroll
@@ -2269,7 +2315,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
 #pragma unroll
                         for (int w = 0; w < J; ++w) {
                             const int j = dirc > 0 ? w : J - 1 - w;
-                            rag_walk_global(l, __builtin_amdgcn_readlane(nrag_v, j), nrmax, __double2loint(ragm.e), __double2hiint(ragm.e), ragm.ro,
+                            rag_walk_global(l, ph, __builtin_amdgcn_readlane(nrag_v, j), nrmax, __double2loint(ragm.e), __double2hiint(ragm.e), ragm.ro,
                                             lane8, Rb, rag_R0, rag_R1, rag_R2, r1, r2, r3);
                             const double f = F[j];
                             farg[j] = fma(-f, fma(-f, fma(-f, r3, r2), r1), farg[j]);
@@ -2360,6 +2406,7 @@ __global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(Sca
                     }
                 }
                 PROF_MARK(5);
+                // (round 4, measured and dropped: E by an LDS broadcast read one batch ahead instead of two v_readlane per entry: -0.7 %)
                 // series entries: p_k += (E R)^k up to the order the entry's class needs.  The wave reads them all at once, lanes over
                 // entries; one entry at a time then comes out of the registers (readlane) -- its R is the only load in the loop, four
                 // entries ahead.  The producer sorted them by class, highest first: one branch-free loop per class (a lower-class
