@@ -19,14 +19,18 @@ lo, hi = np.zeros(M, np.int64), np.full(M, N - 1, np.int64)
 rows = model.rows_of(k, nn)
 As_sorted = sorted(As)
 print('A grid:', As_sorted)
-tot = 0.0
-for name, sub in (('all', As), ('A<1e3', [a for a in As if a < 1e3]), ('1e3<=A<1e4', [a for a in As if 1e3 <= a < 1e4]),
-                  ('1e4<=A<1e5', [a for a in As if 1e4 <= a < 1e5]), ('A>=1e5', [a for a in As if a >= 1e5])):
+zcut = 18.420680743952367
+groups = [('all', As), ('A<1e3', [a for a in As if a < 1e3]), ('1e3<=A<1e4', [a for a in As if 1e3 <= a < 1e4]),
+          ('1e4<=A<1e5', [a for a in As if 1e4 <= a < 1e5]), ('A>=1e5', [a for a in As if a >= 1e5])]
+if len(sys.argv) > 2 and sys.argv[2] == 'each':
+    groups = [('all', As)] + [('A=%g' % a, [a]) for a in As_sorted]
+for name, sub in groups:
     ctx = eng.Context(0)
     ctx.set_model(model, sub)
     ctx.set_sites(gen, rows)
     ctx.set_variant(variant)
     ctx.set_tests(gen[idx], lo, hi)
     ctx.scan(); ctx.sync(); ctx.scan(); ctx.sync()
-    print('%-12s %2d values: %.2f ms' % (name, len(sub), ctx.last_scan_ms()))
+    sites = sum(float(np.mean(np.searchsorted(gen, gen[idx] + zcut / a, 'right') - np.searchsorted(gen, gen[idx] - zcut / a, 'left'))) for a in sub)
+    print('%-12s %2d values: %8.2f ms   %9.1f sites per window (summed over the A values)' % (name, len(sub), ctx.last_scan_ms(), sites))
     ctx.close()
