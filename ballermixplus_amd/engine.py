@@ -57,11 +57,22 @@ class ModelArrays:
 
     def rows_of(self, count, total):
         """LUT row of every site: row_off[n] + k."""
-        total = np.asarray(total, dtype=np.int64)
-        count = np.asarray(count, dtype=np.int64)
-        un, inv = np.unique(total, return_inverse=True)
-        offs = np.array([self._off_of[int(n)] for n in un], dtype=np.int64)
-        return _lib.i32(offs[inv] + count)
+        total = np.asarray(total)
+        count = np.asarray(count)
+        if total.size == 0:
+            return _lib.i32(np.zeros(0, dtype=np.int64))
+        lo, hi = int(total.min()), int(total.max())
+        if lo < 0:
+            raise KeyError(lo)
+        tab = np.full(hi + 1, -1, dtype=np.int32)         # sample size -> first row; one gather instead of a sort of all sites
+        for n, off in self._off_of.items():
+            if 0 <= n <= hi:
+                tab[n] = off
+        rows = tab[total]
+        if rows.min() < 0:
+            raise KeyError(int(total[int(np.argmin(rows))]))
+        rows += count.astype(np.int32, copy=False)
+        return _lib.i32(rows)
 
 
 class Context:

@@ -33,6 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector FP64: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+MEASURED_FMA_STREAM_TFLOPS = 66.6     # pure FP64 FMA stream, 2 waves per SIMD, all CUs: scripts/ubench_dep.hip on MI355X
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6300 achievable)
 SURVEY_FLOP_PER_EVAL = 32        # SURVEY.md 8(d) convention for the reference's FMA + log1p form
 CALIBRATION = os.path.join(REPO, 'profiles', 'r04_pmc_calibration.json')
@@ -55,8 +56,8 @@ def parse_args(argv=None):
     ap.add_argument('--variant', type=int, default=0)
     ap.add_argument('--step', type=int, default=1, help='test site = every step-th SNP (the reference\'s -s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-cold-pass', action='store_true', help='skip the cold end-to-end pass after the timed steps (PMC runs: the counters '
-                                                                'must see exactly the timed step)')
+    ap.add_argument('--no-cold-pass', action='store_true', help='no extra (cold) first step before the warm-up steps and no end_to_end_* figures (PMC runs: the '
+                                                                'counters must see exactly the timed step)')
     ap.add_argument('--no-parity-sample', action='store_true', help='skip the oracle check of 256 windows of the last step (outside the timed region)')
     ap.add_argument('--cpu-seconds', type=float, default=24.0, help='budget of the faithful CPU port (both legs together)')
     return ap.parse_args(argv)
@@ -438,9 +439,13 @@ def _run(args):
     zcut = _lib.lib().bmx_alpha_cut()
 
     # ONE resident context: the table, and per chromosome (slot) the site arrays and this rank's test sites, in HBM from here on
+    # (t_abi: wall clock inside the calls a user of the C ABI makes once per genome -- context, table build, uploads, test-site location
+    # and planning; with the first step below it is the COLD pass the line reports as end_to_end_*)
+    t_abi = time.perf_counter()
     ctx = engine.Context(dev)
     ctx.set_variant(args.variant)
     ctx.set_model(model, As)
+    t_abi = time.perf_counter() - t_abi
     slots, counts_by_rank = [], np.zeros(world.size, dtype=np.int64)
     evals_per_step, bytes_per_step, windows_per_step, plan = 0.0, 0.0, 0, None
     layout = []                                   # rank 0: (chromosome, per-rank test-site counts) in slot order
@@ -456,10 +461,14 @@ def _run(args):
             mine, cnts = tidx, [len(tidx)] * world.size
         counts_by_rank += np.asarray(cnts)
         layout.append(cnts)
+        t_c = time.perf_counter()
         ctx.select_slot(ci)
         ctx.set_sites(gen, model.rows_of(k, nn))
         if len(mine):
-            ctx.set_tests(gen[mine], np.zeros(len(mine), np.int64), np.full(len(mine), Nc - 1, np.int64))
+            tg = gen[::args.step] if len(mine) == len(tidx) else gen[mine]        # (every test site is this rank's: a view, no gather of 40 M positions)
+            ctx.set_tests(tg, np.zeros(len(mine), np.int64), np.full(len(mine), Nc - 1, np.int64))
+        t_abi += time.perf_counter() - t_c
+        if len(mine):
             slots.append(ci)
             if plan is None:
                 plan = ctx.plan()
@@ -537,6 +546,17 @@ def _run(args):
                 kernel_ms.append(ctx.last_scan_ms())
         return got
 
+    # ---- the COLD pass: everything above that a caller of the C ABI pays once per genome (t_abi) plus the FIRST step on the fresh
+    # context (scans + result transfer, first-touch costs included); untimed, before the warm-up steps
+    t_cold, cold = None, None
+    if not args.no_cold_pass:
+        barrier()
+        t0 = time.perf_counter()
+        cold = one_step()
+        barrier()
+        t_cold = t_abi + time.perf_counter() - t0
+        if rank == 0:
+            cold = [np.array(g, copy=True) for g in cold]       # the transfer buffers are reused by the next step
     for _ in range(args.warmup):
         one_step()
     kernel_ms = []
@@ -553,34 +573,6 @@ def _run(args):
     else:
         k_total = float(sum(kernel_ms))
 
-    if rank == 0:
-        last = [np.array(g, copy=True) for g in last]       # the cold pass below reuses the transfer buffers
-    # ---- one COLD pass, outside the timed steps: a fresh context given host buffers -- table build (K1), uploads, test-site
-    # location, the planning / counting pass, the scans, the result transfer (what a caller of the C ABI pays once per genome)
-    t_cold, cold = None, None
-    if not args.no_cold_pass:
-        if native['comm'] is not None:
-            native['comm'].close()
-        ctx.close()
-        barrier()
-        t0 = time.perf_counter()
-        ctx = engine.Context(dev)
-        if native['comm'] is not None:
-            native['comm'].close()
-            native['comm'] = world.native_comm(ctx)
-        ctx.set_variant(args.variant)
-        ctx.set_model(model, As)
-        for ci, (gen, k, nn) in enumerate(chroms):
-            Nc = len(gen)
-            tidx = np.arange(0, Nc, args.step)
-            mine = tidx[distributed.assign(len(tidx), world.size)[rank]] if sharded else tidx
-            ctx.select_slot(ci)
-            ctx.set_sites(gen, model.rows_of(k, nn))
-            if len(mine):
-                ctx.set_tests(gen[mine], np.zeros(len(mine), np.int64), np.full(len(mine), Nc - 1, np.int64))
-        cold = one_step()
-        barrier()
-        t_cold = time.perf_counter() - t0
     if world.distributed and t_cold is not None:
         tc = torch.tensor([t_cold], dtype=torch.float64, device=tdev if on_gpu else torch.device('cpu'))
         torch.distributed.all_reduce(tc, op=torch.distributed.ReduceOp.MAX)
@@ -631,9 +623,12 @@ def _run(args):
                        'checksum_clr': checksum,
                        'end_to_end_windows_per_s': windows_per_step / t_cold if t_cold else None,
                        'end_to_end_seconds': t_cold,
-                       'end_to_end_note': 'one cold pass outside the timed steps: fresh context from host buffers -- table build (K1), '
-                                          'H2D of all site arrays and test sites, test-site location + planning / counting pass, the scans, the '
-                                          'result records to the host (N > 1: the gather); records bitwise equal to the timed steps\': %s' % cold_same,
+                       'end_to_end_setup_seconds_rank0': t_abi if t_cold else None,
+                       'end_to_end_note': 'the COLD pass of this run, outside the timed steps: from host buffers through the calls a user of the C '
+                                          'ABI makes once per genome -- context creation, table build (K1), H2D of all site arrays and test sites, '
+                                          'test-site location + planning / counting pass (wall clock inside those calls) -- plus the FIRST step on '
+                                          'the fresh context: the scans and the result records to the host (N > 1: the gather); slowest rank; records '
+                                          'bitwise equal to the timed steps\': %s' % cold_same,
                        'input_sha256': digest.hexdigest(),
                        'library_build': build_id,
                        'plan_seconds_outside_timed_region': t_plan,
@@ -670,6 +665,11 @@ def _run(args):
             r['valu_insts_per_64_evals'] = cal['valu_per_64_evals']
             r['valu_issue_tflops_equiv'] = evals_s * cal['valu_per_64_evals'] * 128 / 64 / 1e12
             r['valu_issue_frac'] = r['valu_issue_tflops_equiv'] / FP64_VALU_PEAK_TFLOPS
+            # what a pure v_fma_f64 stream reaches on this chip at two waves per SIMD (scripts/ubench_dep.hip: 4.45 cycles per
+            # instruction at a core clock that falls to 2.26 GHz under it; profiles/r04_ubench_dependent_fp64.txt) -- context for
+            # `frac`, which stays against the nominal peak
+            r['measured_fma_stream_tflops'] = MEASURED_FMA_STREAM_TFLOPS
+            r['frac_of_measured_fma_stream'] = r['achieved'] / MEASURED_FMA_STREAM_TFLOPS
             r['calibration'] = cal['source']
             # HBM traffic of one average launch, from the PMC counters per window (FETCH_SIZE doubled as the guide
             # prescribes for gfx950, WRITE_SIZE as read)
