@@ -441,10 +441,18 @@ def _run(args):
     # ONE resident context: the table, and per chromosome (slot) the site arrays and this rank's test sites, in HBM from here on
     # (t_abi: wall clock inside the calls a user of the C ABI makes once per genome -- context, table build, uploads, test-site location
     # and planning; with the first step below it is the COLD pass the line reports as end_to_end_*)
-    t_abi = time.perf_counter()
+    phases = {}
+
+    def lap(name, since):
+        phases[name] = phases.get(name, 0.0) + time.perf_counter() - since
+        return time.perf_counter()
+
+    t_abi = t_c = time.perf_counter()
     ctx = engine.Context(dev)
+    t_c = lap('context', t_c)
     ctx.set_variant(args.variant)
     ctx.set_model(model, As)
+    lap('table_build', t_c)
     t_abi = time.perf_counter() - t_abi
     slots, counts_by_rank = [], np.zeros(world.size, dtype=np.int64)
     evals_per_step, bytes_per_step, windows_per_step, plan = 0.0, 0.0, 0, None
@@ -461,13 +469,19 @@ def _run(args):
             mine, cnts = tidx, [len(tidx)] * world.size
         counts_by_rank += np.asarray(cnts)
         layout.append(cnts)
-        t_c = time.perf_counter()
+        t_c = t_c0 = time.perf_counter()
         ctx.select_slot(ci)
-        ctx.set_sites(gen, model.rows_of(k, nn))
+        rows_c = model.rows_of(k, nn)
+        t_c = lap('host_row_lookup', t_c)
+        ctx.set_sites(gen, rows_c)
+        t_c = lap('site_uploads', t_c)
         if len(mine):
             tg = gen[::args.step] if len(mine) == len(tidx) else gen[mine]        # (every test site is this rank's: a view, no gather of 40 M positions)
-            ctx.set_tests(tg, np.zeros(len(mine), np.int64), np.full(len(mine), Nc - 1, np.int64))
-        t_abi += time.perf_counter() - t_c
+            w_lo, w_hi = np.zeros(len(mine), np.int64), np.full(len(mine), Nc - 1, np.int64)
+            t_c = lap('host_test_site_arrays', t_c)
+            ctx.set_tests(tg, w_lo, w_hi)
+            lap('test_sites_upload_locate_plan', t_c)
+        t_abi += time.perf_counter() - t_c0
         if len(mine):
             slots.append(ci)
             if plan is None:
@@ -554,7 +568,8 @@ def _run(args):
         t0 = time.perf_counter()
         cold = one_step()
         barrier()
-        t_cold = t_abi + time.perf_counter() - t0
+        phases['first_step'] = time.perf_counter() - t0
+        t_cold = t_abi + phases['first_step']
         if rank == 0:
             cold = [np.array(g, copy=True) for g in cold]       # the transfer buffers are reused by the next step
     for _ in range(args.warmup):
@@ -623,7 +638,7 @@ def _run(args):
                        'checksum_clr': checksum,
                        'end_to_end_windows_per_s': windows_per_step / t_cold if t_cold else None,
                        'end_to_end_seconds': t_cold,
-                       'end_to_end_setup_seconds_rank0': t_abi if t_cold else None,
+                       'end_to_end_phases_rank0': {k_: round(v_, 4) for k_, v_ in phases.items()} if t_cold else None,
                        'end_to_end_note': 'the COLD pass of this run, outside the timed steps: from host buffers through the calls a user of the C '
                                           'ABI makes once per genome -- context creation, table build (K1), H2D of all site arrays and test sites, '
                                           'test-site location + planning / counting pass (wall clock inside those calls) -- plus the FIRST step on '
