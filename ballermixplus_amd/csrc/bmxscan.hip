@@ -95,6 +95,7 @@ bool trace_on() {
 constexpr int WAVE = 64;
 constexpr int SCAN_THREADS = 256;             // 4 waves per workgroup (default)
 constexpr int SCAN_THREADS_MAX = 512;         // 8 waves when one R slice fills most of a CU's LDS
+constexpr int SCAN_THREADS_J8 = 768;          // 12 waves = 3 per SIMD: the prepared kernel's 8-test-site form (168 registers)
 constexpr int SITE_THREADS = 1024;            // per-site kernel: 16 waves per workgroup, two workgroups per CU = 8 waves per SIMD
                                               // (62 VGPRs; the kernel is latency-bound per pass and lives on occupancy)
 constexpr int LDS_LIMIT_BYTES = 160 * 1024;   // gfx950: 160 KiB per CU
@@ -260,6 +261,14 @@ __global__ void locate_kernel(const double *genpos, int64_t N, const double *tes
         if (genpos[m] <= v) a = m + 1; else b = m;
     }
     center_hi[t] = a;  // first index with genpos > test position (sites in between are ties)
+}
+
+// window bounds of the all-sites mode (set_tests without bounds): every window is [0, N - 1]
+__global__ void all_sites_kernel(int64_t *lo, int64_t *hi, int64_t M, int64_t N) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    lo[k] = 0;
+    hi[k] = N - 1;
 }
 
 // index gaps between neighbouring test sites at a strided sample of all of them (set_tests: test-site density)
@@ -1428,7 +1437,7 @@ constexpr int RING_UNITS = 256, RING_MIRROR = 32, AUX_UNITS = 32;     // per wav
 constexpr int PREP_ZONE_DONE = -0x7fffffff;
 constexpr int PREP_THREADS = 256;
 constexpr int PREP_THR_LDS_MAX = 4096;                                // rows whose far thresholds are staged in LDS
-constexpr int64_t SOLO_GAP = 9;                                       // median gap between test sites beyond which groups stop paying (round 4: J = 8 1.66 / 1.54 M, solo 1.57 / 1.58 M windows/s at stride 9 / 10)
+constexpr int64_t SOLO_GAP = 10;                                      // median gap between test sites beyond which groups stop paying (round 4, J = 8 at three waves per SIMD: 1.64 / 1.55 M, solo 1.575 / 1.574 M windows/s at stride 10 / 11)
 
 struct PrepParams {
     const double *genpos;
@@ -1946,8 +1955,10 @@ struct PrepView {
     int *status;
 };
 
+// (groups of 8 with the table in LDS: 168 registers, so that one workgroup of twelve waves -- one R slice, twelve rings -- gives
+// three waves per SIMD; the 16-test-site form needs 243 and runs two)
 template <int J, bool USE_LDS>
-__global__ __launch_bounds__(SCAN_THREADS_MAX) void clr_scan_prepared_kernel(ScanParams P, PrepView V) {
+__global__ __launch_bounds__((J == 8 && USE_LDS) ? SCAN_THREADS_J8 : SCAN_THREADS_MAX) void clr_scan_prepared_kernel(ScanParams P, PrepView V) {
 #ifdef BMX_PROFILE
     // sections: 0 sites between the test sites, 1 zone header, 2 pair list, 3 quad list, 4 generic walks past the zones, 5 fold of the
     // moments, 6 series entries, 7 ragged end + Horner, 8 exp + apply, 9 renormalise + best-tracking, 10 group set-up, 11 winners out
@@ -3743,14 +3754,22 @@ int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64
     if (!c) return fail(BMX_E_INVALID, "ctx is NULL");
     ChromSlot *s = c->cur;
     if (!s->has_sites) return fail(BMX_E_STATE, "set_sites must precede set_tests");
-    if (M < 1 || !test_gen || !win_lo || !win_hi) return fail(BMX_E_INVALID, "empty test-site arrays");
+    if (M < 1 || !test_gen) return fail(BMX_E_INVALID, "empty test-site arrays");
+    if ((win_lo == nullptr) != (win_hi == nullptr)) return fail(BMX_E_INVALID, "window bounds: both arrays or neither (neither = all sites)");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     drop_tests(s);
     int rc;
     if ((rc = upload(s->test_gen, test_gen, (size_t)M, c->stream))) return rc;
-    if ((rc = upload(s->win_lo, win_lo, (size_t)M, c->stream))) return rc;
-    if ((rc = upload(s->win_hi, win_hi, (size_t)M, c->stream))) return rc;
+    if (win_lo) {
+        if ((rc = upload(s->win_lo, win_lo, (size_t)M, c->stream))) return rc;
+        if ((rc = upload(s->win_hi, win_hi, (size_t)M, c->stream))) return rc;
+    } else {        // the reference's default mode (v1:598-610): every window holds all sites -- nothing to copy
+        HIP_TRY(s->win_lo.ensure((size_t)M));
+        HIP_TRY(s->win_hi.ensure((size_t)M));
+        hipLaunchKernelGGL(all_sites_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, c->stream, s->win_lo.p, s->win_hi.p, M, s->N);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(s->center.ensure((size_t)M));
     HIP_TRY(s->center_hi.ensure((size_t)M));
     HIP_TRY(s->clr.ensure((size_t)M));
@@ -3904,6 +3923,16 @@ int plan_scan(bmx_ctx *c, ChromSlot *s, ScanPlan &pl) {
         threads = SCAN_THREADS_MAX;
         lds_bytes = (use_lds ? lds + lds_rm : 0) + (size_t)(threads / WAVE) * wave_bytes(mom_slots);
         spb *= 2;
+    }
+    if (prepared && J == 8 && use_lds) {
+        // three waves per SIMD: ONE workgroup of twelve waves per CU (its registers allow it, see the kernel), if slice + twelve rings fit
+        const size_t lds12 = lds + (size_t)(SCAN_THREADS_J8 / WAVE) * wave_bytes(mom_slots);
+        if (lds12 <= (size_t)LDS_LIMIT_BYTES) {
+            if (threads == SCAN_THREADS_MAX) spb /= 2;
+            threads = SCAN_THREADS_J8;
+            lds_bytes = lds12;
+            spb = spb * 3;                 // the same number of groups per wave as with four waves
+        }
     }
     if (!J) {       // per-site kernels: 16 waves, the R slice (if it fits) + 1 KB of scratch list (solo: 4.3 KB of ring) per wave
         threads = SITE_THREADS;

@@ -113,10 +113,15 @@ class Context:
         self._slot_M.pop(self.slot, None)
         _lib.check(self._L.bmx_ctx_set_sites(self._h, len(g), _lib.as_dp(g), _lib.as_ip(r)))
 
-    def set_tests(self, test_gen, win_lo, win_hi):
-        t, lo, hi = _lib.f64(test_gen), _lib.i64(win_lo), _lib.i64(win_hi)
+    def set_tests(self, test_gen, win_lo=None, win_hi=None):
+        """Test positions and their inclusive index windows; no windows = all sites of the chromosome (the reference's default mode)."""
+        t = _lib.f64(test_gen)
         self.M = len(t)
         self._slot_M[self.slot] = self.M
+        if win_lo is None and win_hi is None:
+            _lib.check(self._L.bmx_ctx_set_tests(self._h, len(t), _lib.as_dp(t), None, None))
+            return
+        lo, hi = _lib.i64(win_lo), _lib.i64(win_hi)
         _lib.check(self._L.bmx_ctx_set_tests(self._h, len(t), _lib.as_dp(t), _lib.as_lp(lo), _lib.as_lp(hi)))
 
     def set_variant(self, v):

@@ -477,9 +477,7 @@ def _run(args):
         t_c = lap('site_uploads', t_c)
         if len(mine):
             tg = gen[::args.step] if len(mine) == len(tidx) else gen[mine]        # (every test site is this rank's: a view, no gather of 40 M positions)
-            w_lo, w_hi = np.zeros(len(mine), np.int64), np.full(len(mine), Nc - 1, np.int64)
-            t_c = lap('host_test_site_arrays', t_c)
-            ctx.set_tests(tg, w_lo, w_hi)
+            ctx.set_tests(tg)                 # no window bounds: every window holds all sites (the reference's default mode)
             lap('test_sites_upload_locate_plan', t_c)
         t_abi += time.perf_counter() - t_c0
         if len(mine):

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define BMX_ABI_VERSION_MAJOR 1
-#define BMX_ABI_VERSION_MINOR 4
+#define BMX_ABI_VERSION_MINOR 5
 
 enum {
     BMX_OK = 0,
@@ -143,7 +143,9 @@ int bmx_ctx_set_model(bmx_ctx *c, const bmx_model *m, const double *A, int32_t n
 /* Copy the site arrays of one chromosome to the device (and rank its rows by frequency for the scan
  * kernel's far-field moments). */
 int bmx_ctx_set_sites(bmx_ctx *c, int64_t N, const double *genpos, const int32_t *row);
-/* Copy test sites + window bounds to the device (and locate each test site). */
+/* Copy test sites + window bounds to the device (and locate each test site).  win_lo == win_hi == NULL: every window
+ * holds all sites of the chromosome, [0, N - 1] -- the reference's default mode (Scan._alpha, BalLeRMix+_v1.py:598-610);
+ * the bounds are then written on the device, nothing is copied. */
 int bmx_ctx_set_tests(bmx_ctx *c, int64_t M, const double *test_gen, const int64_t *win_lo,
                       const int64_t *win_hi);
 /* Launch the scan (K2 + argmax finalisation) on the context's stream; asynchronous. */

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert n in _lib.PROTOTYPES, 'ctypes prototype missing for ' + n
     major, minor = C.c_int(), C.c_int()
     L.bmx_version(C.byref(major), C.byref(minor))
-    assert (major.value, minor.value) == (1, 4)
+    assert (major.value, minor.value) == (1, 5)
     assert L.bmx_build_id().decode() == _lib.source_id()      # the binary under test was built from this tree
     assert L.bmx_alpha_cut() == 18.420680743952364
 

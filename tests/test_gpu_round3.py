@@ -27,8 +27,8 @@ def _synth_model(n=100, chroms=((1, 200000),), bal=False):
 
 
 def test_plan_names_the_kernel_that_runs():
-    """bmx_ctx_plan: dense test sites -> prepared pipeline, J = 16, table in LDS; every 8th SNP -> J = 8; every 10th (round 4: the
-    measured crossover moved from a gap of 12 to 9), 13th or 200th -> one test site per wave, prepared (solo); variant 2 -> the
+    """bmx_ctx_plan: dense test sites -> prepared pipeline, J = 16, table in LDS; every 8th or 10th SNP -> J = 8; every 11th (round 4: the
+    measured crossover moved from a gap of 12 to 10), 13th or 200th -> one test site per wave, prepared (solo); variant 2 -> the
     round-2 per-site kernel; variant 12 -> the round-2 grouped kernel."""
     eng, data, model, (xs, ab, As) = _synth_model()
     phys, gen, k, nn = data[0]
@@ -37,7 +37,7 @@ def test_plan_names_the_kernel_that_runs():
     ctx.set_model(model, As)
     ctx.set_sites(gen, model.rows_of(k, nn))
     want = {1: ('clr_scan_prepared_kernel<16,true>', 4), 3: ('clr_scan_prepared_kernel<16,true>', 4), 8: ('clr_scan_prepared_kernel<8,true>', 4),
-            9: ('clr_scan_prepared_kernel<8,true>', 4), 10: ('clr_scan_solo_kernel<true>', 5), 13: ('clr_scan_solo_kernel<true>', 5),
+            10: ('clr_scan_prepared_kernel<8,true>', 4), 11: ('clr_scan_solo_kernel<true>', 5), 13: ('clr_scan_solo_kernel<true>', 5),
             200: ('clr_scan_solo_kernel<true>', 5)}
     for step, (name, mode) in want.items():
         idx = np.arange(0, N, step)

@@ -213,3 +213,34 @@ def test_bench_step_through_the_native_gather():
     assert r1.returncode == 0, r1.stderr[-2000:]
     d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith('{')][-1])
     assert d1['config']['checksum_clr'] == pytest.approx(d['config']['checksum_clr'], rel=1e-12)
+
+
+def test_set_tests_without_window_bounds_means_all_sites():
+    """bmx_ctx_set_tests(win_lo = win_hi = NULL): every window holds all sites of the chromosome (Scan._alpha, BalLeRMix+_v1.py:598-610;
+    the bounds are written on the device) -- the records are those of explicit [0, N - 1] bounds, bit for bit, at stride 1 (groups
+    of 16), stride 5 (groups of 8) and stride 40 (one test site per wave); one of the two bounds alone is refused."""
+    from ballermixplus_amd import engine as eng, synth
+    from ballermixplus_amd.hostmodel import Grids
+    N, n = 200000, 100
+    phys, gen, k, nn = synth.synth_chromosome(N, n, 3)
+    spect = {(a, b): f for a, b, f in synth.spect_from_counts(k, nn)}
+    xs, ab, As = Grids(None, None, False, False, None, None).scan_order()
+    model = eng.ModelArrays('B2', int(k.min()), [n], spect, {n: 1.0}, xs, ab)
+    ctx = eng.Context(0)
+    ctx.set_model(model, As)
+    ctx.set_sites(gen, model.rows_of(k, nn))
+    for step, kernel in ((1, 'clr_scan_prepared_kernel<16,true>'), (5, 'clr_scan_prepared_kernel<8,true>'), (40, 'clr_scan_solo_kernel<true>')):
+        idx = np.arange(1000, 150000, step)[:20000]
+        ctx.set_tests(gen[idx], np.zeros(len(idx), np.int64), np.full(len(idx), N - 1, np.int64))
+        assert ctx.plan()['kernel'] == kernel
+        ctx.scan()
+        want = ctx.fetch_records().copy()
+        ctx.set_tests(gen[idx])
+        ctx.scan()
+        got = ctx.fetch_records()
+        assert np.array_equal(got, want), step
+    from ballermixplus_amd import _lib
+    t = _lib.f64(gen[:16])
+    with pytest.raises(Exception):
+        _lib.check(ctx._L.bmx_ctx_set_tests(ctx._h, 16, _lib.as_dp(t), _lib.as_lp(np.zeros(16, np.int64)), None))
+    ctx.close()
